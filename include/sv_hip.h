@@ -1,0 +1,200 @@
+/*
+ * sv_hip.h — C-ABI of libsvhip.so, the MI355X (gfx950) sparse-voxel inference library.
+ *
+ * This is the drop-in boundary for the hot path of bcsefercik/markerless-robot-camera-calibration
+ * (SURVEY.md §8b): everything the reference gets from MinkowskiEngine 0.5.4 / numpy LAPACK on the
+ * path  voxelise -> sparse U-Net -> slice/argmax -> Kabsch  is exported here as plain C functions.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (memory owned by the caller, normally a PyTorch-ROCm tensor)
+ *    unless the name ends in _host;
+ *  - `stream` is a hipStream_t passed as void*; NULL = the default stream;
+ *  - the library allocates nothing persistent: temporaries come from a caller-supplied workspace whose
+ *    size is returned by the matching *_workspace_bytes();
+ *  - return value: 0 = OK, <0 = error (SV_ERR_*); sv_last_error() gives the message (thread-local);
+ *  - dynamic sizes (number of voxels ...) are written to a small device `counters` array the caller
+ *    reads back (one D2H copy), never returned through host pointers, so calls stay asynchronous.
+ *
+ * Row order of every coordinate map is CANONICAL: ascending 64-bit key
+ *    key = batch << 54 | morton3(x + 2^17, y + 2^17, z + 2^17)       (x in bit 3j, y in 3j+1, z in 3j+2)
+ * so a stride-2 parent key is the child key with 3 low Morton bits cleared and children of one parent are
+ * contiguous rows.  (MinkowskiEngine leaves row order unspecified — SURVEY.md Appendix B.2.)
+ *
+ * Kernel-offset numbering (index into W[K][Cin][Cout]):
+ *    kernel_size 3:  k = (dx+1) + 3*(dy+1) + 9*(dz+1),  dx,dy,dz in {-1,0,1}   (x fastest)
+ *    kernel_size 2:  k = dx + 2*dy + 4*dz,              dx,dy,dz in {0,1}
+ *    transposed kernel_size 2 stride 2: the fine voxel c with parent p uses k of (c - p) / tensor_stride.
+ */
+#ifndef SV_HIP_H
+#define SV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SV_OK 0
+#define SV_ERR_INVALID (-1)   /* bad shape / null pointer / unsupported parameter */
+#define SV_ERR_WORKSPACE (-2) /* workspace too small */
+#define SV_ERR_HIP (-3)       /* HIP runtime error, see sv_last_error() */
+#define SV_ERR_RANGE (-4)     /* coordinate or batch index outside the key range (reported in counters) */
+
+#define SV_ACT_NONE 0
+#define SV_ACT_RELU 1
+#define SV_ACT_LEAKY_RELU 2
+
+#define SV_POOL_MAX 0
+#define SV_POOL_AVG 1
+
+#define SV_REDUCE_MEAN 0  /* ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE */
+#define SV_REDUCE_FIRST 1 /* ME.utils.sparse_quantize: lowest original index represents the voxel */
+
+#define SV_TILE_ROWS 128 /* output rows per conv tile; plans are padded to a multiple of this */
+#define SV_COORD_BIAS 131072 /* 2^17 */
+#define SV_COORD_BITS 18
+#define SV_MAX_BATCH 1024
+
+typedef void* sv_stream_t;
+
+const char* sv_last_error(void);
+int sv_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * A1/A2  voxelisation   (replaces ME.TensorField(...).sparse(), ME.SparseTensor(coordinates=...),
+ *        ME.utils.sparse_quantize; reference call sites app/inference_engine.py:405-415,446-454,540-549,
+ *        test_segmentation.py:62-70, data/alivev2.py:290-296, train_segmentation.py:78)
+ *
+ * coords4: float32[N,4] rows (batch, x, y, z) already multiplied by `scale` by the caller, exactly what
+ *          ME.utils.batched_coordinates hands to TensorField.  voxel = floor(coord) per axis.
+ *          With coords_are_int != 0 the buffer is int32[N,4] (already quantised coordinates).
+ * keys:    uint64[N]    first V entries = canonical sorted unique keys
+ * vcoords: int32[N,4]   first V rows   = (batch,x,y,z) of each voxel
+ * inverse: int64[N]     voxel row of every input point  (TensorField -> SparseTensor inverse map)
+ * order:   int32[N]     point indices sorted by (key, original index)  (stable)
+ * seg_start:int32[N+1]  first V+1 entries: voxel v owns order[seg_start[v] .. seg_start[v+1])
+ * counters:int32[4]     [0] = V, [1] = number of out-of-range points (must be 0), [2..3] reserved
+ * ------------------------------------------------------------------------------------------- */
+size_t sv_voxelize_workspace_bytes(int64_t N);
+int sv_voxelize(const void* coords4, int coords_are_int, int64_t N, void* workspace, size_t workspace_bytes,
+                uint64_t* keys, int32_t* vcoords, int64_t* inverse, int32_t* order, int32_t* seg_start,
+                int32_t* counters, sv_stream_t stream);
+
+/* per-voxel feature reduction: out[v][c] = mean (or first) of feats[order[j]][c], j in the voxel's segment,
+ * summed sequentially in ascending original point index (deterministic). */
+int sv_voxel_reduce(const float* feats, int C, const int32_t* order, const int32_t* seg_start, int64_t V, int mode,
+                    float* out, sv_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Coordinate manager pieces (replace ME's coordinate_map_gpu / kernel_map; implicit in every
+ * ME.MinkowskiConvolution call of model/backbone/minkunet.py:55-121)
+ * ------------------------------------------------------------------------------------------- */
+/* open-addressing hash  key -> row ;  capacity must be a power of two >= 2*V. */
+int sv_hash_build(const uint64_t* keys, int64_t V, uint64_t* table_keys, int32_t* table_vals, int64_t capacity,
+                  sv_stream_t stream);
+
+/* stride-2 coordinate map of a map at tensor stride 2^level:  out coord = floor(c / 2^(level+1)) * 2^(level+1).
+ * parent: int32[V_in] row of each input voxel in the output map.  child_start: int32[V_in+1] (first V_out+1 used).
+ * counters[0] = V_out. */
+size_t sv_stride_map_workspace_bytes(int64_t V_in);
+int sv_stride_map(const uint64_t* keys_in, int64_t V_in, int level, void* workspace, size_t workspace_bytes,
+                  uint64_t* keys_out, int32_t* vcoords_out, int32_t* parent, int32_t* child_start, int32_t* counters,
+                  sv_stream_t stream);
+
+/* 27-offset neighbour table of a map with itself (kernel_size 3, stride 1):
+ * nbr[k*ld + o] = row of voxel at coords[o] + offset_k * tensor_stride * dilation, or -1.   mask[o] bit k = present. */
+int sv_kernel_map_k3(const int32_t* vcoords, int64_t V, int tensor_stride, int dilation, const uint64_t* table_keys,
+                     const int32_t* table_vals, int64_t capacity, int32_t* nbr, int64_t ld, uint32_t* mask,
+                     sv_stream_t stream);
+/* kernel_size 2 stride 2 (down): out rows = coarse voxels; nbr[k*ld + p] = fine row of child k of p, or -1. */
+int sv_kernel_map_down(const uint64_t* keys_fine, const int32_t* parent, int64_t V_fine, int level, int64_t V_coarse,
+                       int32_t* nbr, int64_t ld, uint32_t* mask, sv_stream_t stream);
+/* transposed kernel_size 2 stride 2 (up): out rows = fine voxels; nbr[k*ld + i] = parent[i] iff k == child id of i. */
+int sv_kernel_map_up(const uint64_t* keys_fine, const int32_t* parent, int64_t V_fine, int level, int32_t* nbr,
+                     int64_t ld, uint32_t* mask, sv_stream_t stream);
+
+/* Conv execution plan: rows sorted by neighbour mask so that 16-row MFMA sub-tiles share offsets.
+ * perm:    int32[Vpad]        output row handled at sorted position r (-1 = padding)
+ * nbr_s:   int32[K][Vpad]     nbr[k][perm[r]]
+ * submask: uint32[Vpad/128][K] bit s set = sub-tile s (rows 16s..16s+15 of the tile) has a neighbour at offset k
+ * Vpad = round_up(V, 128). */
+size_t sv_plan_workspace_bytes(int64_t V);
+int sv_plan_build(const int32_t* nbr, int64_t ld, const uint32_t* mask, int K, int64_t V, void* workspace,
+                  size_t workspace_bytes, int32_t* perm, int32_t* nbr_s, uint32_t* submask, int64_t Vpad,
+                  sv_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A3/A5  sparse convolution, output stationary, fp32 MFMA, fused epilogue
+ *   (replaces ME.MinkowskiConvolution / ConvolutionTranspose / Linear + MinkowskiBatchNorm(eval) +
+ *    residual add + ReLU/LeakyReLU: model/backbone/minkunet.py:125-187, resnet.py:95-127,
+ *    model/robotnet_segmentation.py:55-64)
+ *
+ *   acc[o][n] = sum over k ascending, c ascending of  in[nbr[k][o]][c] * W[k][c][n]     (one fmaf chain)
+ *   y = acc * scale[n] + shift[n]  (fmaf; scale NULL = 1, shift NULL = 0)   BN(eval) folded / bias
+ *   y += residual[o][n]            (residual NULL = none)
+ *   out[o][n] = act(y)
+ * perm/nbr_s/submask NULL = dense rows (kernel_size 1 / Linear): nbr = identity.
+ * ------------------------------------------------------------------------------------------- */
+int sv_conv_fwd(const float* in, int64_t in_ld, int Cin, const float* W, int K, int Cout, const int32_t* perm,
+                const int32_t* nbr_s, const uint32_t* submask, int64_t V_out, int64_t Vpad, const float* scale,
+                const float* shift, const float* residual, int64_t res_ld, int act, float slope, float* out,
+                int64_t out_ld, sv_stream_t stream);
+
+/* Stand-alone BN(eval)/bias + residual + activation on feature rows, same arithmetic as the conv epilogue:
+ *   out[v][c] = act( fmaf(in[v][c], scale[c], shift[c]) + residual[v][c] )
+ * (ME.MinkowskiBatchNorm / MinkowskiReLU / MinkowskiLeakyReLU when not fused behind a conv, e.g.
+ *  model/robotnet.py:47-50 output_layer, model/robotnet_segmentation.py:60) */
+int sv_affine_act(const float* in, int64_t in_ld, int C, int64_t V, const float* scale, const float* shift,
+                  const float* residual, int64_t res_ld, int act, float slope, float* out, int64_t out_ld,
+                  sv_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A6/A7  pooling, slice, argmax
+ *   (replace ME.MinkowskiGlobalMaxPooling/AvgPooling model/robotnet.py:43, robotnet_encode.py:41;
+ *    SparseTensor.slice app/inference_engine.py:417,551; utils/output.py:67-73)
+ * ------------------------------------------------------------------------------------------- */
+/* batch_start[b] = first row with batch index >= b, b = 0..B  (rows are sorted by batch first). */
+int sv_batch_offsets(const uint64_t* keys, int64_t V, int B, int32_t* batch_start, sv_stream_t stream);
+int sv_global_pool(const float* F, int64_t ld, int C, const int32_t* batch_start, int B, int mode, float* out,
+                   sv_stream_t stream);
+int sv_slice_rows(const float* F, int64_t ld, int C, const int64_t* inverse, int64_t N, float* out,
+                  sv_stream_t stream);
+/* label[i] = first index of the row maximum of F[inverse[i]][0..C), conf[i] = sigmoid(max). */
+int sv_slice_argmax(const float* F, int64_t ld, int C, const int64_t* inverse, int64_t N, int64_t* label,
+                    float* conf, sv_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A9/A10/A12  dense solves, one wavefront per problem, float64
+ *   (replace utils/transformation.py:178-222 get_rigid_transform_3D + :80-84 get_q_from_matrix,
+ *    utils/calibration.py:69-95 compute_quaternions_weighted_average, utils/metrics.py:139-150 compute_ADD_np)
+ * ------------------------------------------------------------------------------------------- */
+/* ref,tgt: double[B][Kmax][3]; K: int32[B] points used per problem (>= 3).  R: double[B][9] row-major,
+ * t: double[B][3], q: double[B][4] (w,x,y,z), sign as scipy's Rotation.from_matrix leaves it. */
+int sv_kabsch_batched(const double* ref, const double* tgt, const int32_t* K, int Kmax, int B, double* R, double* t,
+                      double* q_wxyz, sv_stream_t stream);
+/* Q: double[B][Mmax][4] (w,x,y,z), w: double[B][Mmax], M: int32[B].  out: double[B][4] principal eigenvector of
+ * sum w_i q_i q_i^T / sum w_i, normalised, sign such that the largest-magnitude component is positive. */
+int sv_quat_avg_batched(const double* Q, const double* w, const int32_t* M, int Mmax, int B, double* out,
+                        sv_stream_t stream);
+/* ADD = mean_p || (R_gt p + t_gt) - (R_pr p + t_pr) ||, poses (x,y,z,qw,qx,qy,qz).  points double[B][Pmax][3]. */
+int sv_add_metric_batched(const double* points, const int32_t* P, int Pmax, const double* gt_pose,
+                          const double* pred_pose, int B, double* add_out, sv_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A8  PointNet++ sampling / grouping  (replace model/pointnet2_utils.py:65-86 farthest_point_sample,
+ *      :89-109 query_ball_point, utils/data.py:13-34 numpy FPS)
+ * ------------------------------------------------------------------------------------------- */
+/* xyz float32[B][N][3]; start int64[B] first centroid (the reference draws it at random: pass it in);
+ * out int64[B][S].  Distances are float32 ((dx*dx + dy*dy) + dz*dz, no fma), argmax = first maximum. */
+int sv_fps(const float* xyz, int B, int N, int S, const int64_t* start, int64_t* out, sv_stream_t stream);
+/* out int64[B][S][nsample]: the first nsample indices n (ascending) with ||xyz[n]-new_xyz[s]||^2 <= r^2,
+ * padded with the first hit (r^2 = (float)(radius*radius), as torch compares a float32 tensor with the python
+ * scalar radius**2); the distance uses the reference's expanded form (-2ab + a^2 + b^2) in float32. */
+int sv_ball_query(const float* xyz, const float* new_xyz, int B, int N, int S, double radius, int nsample,
+                  int64_t* out, sv_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SV_HIP_H */

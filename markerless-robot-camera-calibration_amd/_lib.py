@@ -1,0 +1,109 @@
+"""ctypes binding of libsvhip.so (the C-ABI declared in include/sv_hip.h).
+
+There is NO fallback: if the HIP library is missing or a call fails, the product path raises.  PyTorch-ROCm is used
+only to own device memory and streams; every computation on the hot path is a call into the library.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsvhip.so")
+
+SV_ACT_NONE, SV_ACT_RELU, SV_ACT_LEAKY_RELU = 0, 1, 2
+SV_POOL_MAX, SV_POOL_AVG = 0, 1
+SV_REDUCE_MEAN, SV_REDUCE_FIRST = 0, 1
+SV_TILE_ROWS = 128
+SV_COORD_BIAS = 1 << 17
+SV_COORD_BITS = 18
+SV_MAX_BATCH = 1024
+
+
+class SvHipError(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes); kept in one table so tests can check that every symbol of include/sv_hip.h is exported
+_P = c_void_p
+SIGNATURES = {
+    "sv_last_error": (c_char_p, []),
+    "sv_abi_version": (c_int, []),
+    "sv_voxelize_workspace_bytes": (c_size_t, [c_int64]),
+    "sv_voxelize": (c_int, [_P, c_int, c_int64, _P, c_size_t, _P, _P, _P, _P, _P, _P, _P]),
+    "sv_voxel_reduce": (c_int, [_P, c_int, _P, _P, c_int64, c_int, _P, _P]),
+    "sv_hash_build": (c_int, [_P, c_int64, _P, _P, c_int64, _P]),
+    "sv_stride_map_workspace_bytes": (c_size_t, [c_int64]),
+    "sv_stride_map": (c_int, [_P, c_int64, c_int, _P, c_size_t, _P, _P, _P, _P, _P, _P]),
+    "sv_kernel_map_k3": (c_int, [_P, c_int64, c_int, c_int, _P, _P, c_int64, _P, c_int64, _P, _P]),
+    "sv_kernel_map_down": (c_int, [_P, _P, c_int64, c_int, c_int64, _P, c_int64, _P, _P]),
+    "sv_kernel_map_up": (c_int, [_P, _P, c_int64, c_int, _P, c_int64, _P, _P]),
+    "sv_plan_workspace_bytes": (c_size_t, [c_int64]),
+    "sv_plan_build": (c_int, [_P, c_int64, _P, c_int, c_int64, _P, c_size_t, _P, _P, _P, c_int64, _P]),
+    "sv_conv_fwd": (
+        c_int,
+        [_P, c_int64, c_int, _P, c_int, c_int, _P, _P, _P, c_int64, c_int64, _P, _P, _P, c_int64, c_int, c_float, _P,
+         c_int64, _P],
+    ),
+    "sv_affine_act": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, _P, c_int64, c_int, c_float, _P, c_int64, _P]),
+    "sv_batch_offsets": (c_int, [_P, c_int64, c_int, _P, _P]),
+    "sv_global_pool": (c_int, [_P, c_int64, c_int, _P, c_int, c_int, _P, _P]),
+    "sv_slice_rows": (c_int, [_P, c_int64, c_int, _P, c_int64, _P, _P]),
+    "sv_slice_argmax": (c_int, [_P, c_int64, c_int, _P, c_int64, _P, _P, _P]),
+    "sv_kabsch_batched": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P]),
+    "sv_quat_avg_batched": (c_int, [_P, _P, _P, c_int, c_int, _P, _P]),
+    "sv_add_metric_batched": (c_int, [_P, _P, c_int, _P, _P, c_int, _P, _P]),
+    "sv_fps": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
+    "sv_ball_query": (c_int, [_P, _P, c_int, c_int, c_int, c_double, c_int, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libsvhip.so (once).  Raises SvHipError when it has not been built: there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SvHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C markerless-robot-camera-calibration_amd/csrc`). There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc, name):
+    if rc != 0:
+        msg = _lib.sv_last_error().decode("utf-8", "replace")
+        raise SvHipError(f"{name} failed with status {rc}: {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    _check(rc, name)
+
+
+def require_cuda(t, what="tensor"):
+    if not t.is_cuda:
+        raise SvHipError(f"{what} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")
+    return t

@@ -1,0 +1,404 @@
+"""Sparse-tensor runtime behind the MinkowskiEngine names the reference uses.
+
+  TensorField(features, coordinates, quantization_mode, minkowski_algorithm, device).sparse()
+  SparseTensor(features, coordinates=..., device=...)  / .F .C .slice(field) .decomposed_coordinates
+  CoordinateManager: per-frame coordinate maps (stride 1,2,4,...), hash tables, kernel maps and conv plans,
+  shared by every tensor derived from one input (what ME calls the coordinate manager).
+
+Reference call sites: app/inference_engine.py:405-417,446-454,540-551; test_segmentation.py:62-72;
+train_segmentation.py:78; data/alivev2.py:363.  Everything numeric is a libsvhip.so call (include/sv_hip.h).
+"""
+from ctypes import c_float, c_int, c_int64, c_size_t
+from enum import Enum
+
+import torch
+
+from . import _lib
+from ._lib import SV_TILE_ROWS, call, ptr, stream_ptr
+
+
+class SparseTensorQuantizationMode(Enum):
+    RANDOM_SUBSAMPLE = 0
+    UNWEIGHTED_AVERAGE = 1
+    UNWEIGHTED_SUM = 2
+    NO_QUANTIZATION = 3
+
+
+class MinkowskiAlgorithm(Enum):
+    DEFAULT = 0
+    MEMORY_EFFICIENT = 1
+    SPEED_OPTIMIZED = 2
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def _next_pow2(x):
+    p = 1
+    while p < x:
+        p <<= 1
+    return p
+
+
+class CoordinateMap:
+    """Canonical (key-sorted) voxel set at one tensor stride."""
+
+    __slots__ = ("keys", "coords", "V", "stride", "_hash")
+
+    def __init__(self, keys, coords, V, stride):
+        self.keys = keys  # int64 tensor holding the uint64 keys, [V]
+        self.coords = coords  # int32 [V,4] (batch,x,y,z)
+        self.V = V
+        self.stride = stride
+        self._hash = None
+
+    def hash(self):
+        if self._hash is None:
+            cap = _next_pow2(max(2 * self.V, 2))
+            tkeys = torch.empty(cap, dtype=torch.int64, device=self.keys.device)
+            tvals = torch.empty(cap, dtype=torch.int32, device=self.keys.device)
+            call("sv_hash_build", ptr(self.keys), c_int64(self.V), ptr(tkeys), ptr(tvals), c_int64(cap), stream_ptr())
+            self._hash = (tkeys, tvals, cap)
+        return self._hash
+
+
+class ConvPlan:
+    """Mask-sorted execution plan of one kernel map (include/sv_hip.h sv_plan_build)."""
+
+    __slots__ = ("perm", "nbr_s", "submask", "V_out", "Vpad", "K", "pairs")
+
+    def __init__(self, perm, nbr_s, submask, V_out, Vpad, K):
+        self.perm, self.nbr_s, self.submask = perm, nbr_s, submask
+        self.V_out, self.Vpad, self.K = V_out, Vpad, K
+        self.pairs = None  # number of (in,out) pairs, filled lazily for roofline accounting
+
+    def num_pairs(self):
+        if self.pairs is None:
+            self.pairs = int((self.nbr_s >= 0).sum().item())
+        return self.pairs
+
+
+class CoordinateManager:
+    def __init__(self, device):
+        self.device = device
+        self.maps = {}  # stride -> CoordinateMap
+        self.parents = {}  # fine stride -> (parent int32[V_fine], child_start int32[V_coarse+1])
+        self.plans = {}
+        self._batch_offsets = {}
+        self.num_batches = None
+
+    # ---- coordinate maps -------------------------------------------------------------------
+    def stride_map(self, stride):
+        """Map at tensor stride `stride` (power of two); created from the next finer one on demand."""
+        if stride in self.maps:
+            return self.maps[stride]
+        if stride <= 1 or (stride & (stride - 1)):
+            raise _lib.SvHipError(f"no coordinate map at tensor stride {stride}")
+        fine = self.stride_map(stride // 2)
+        level = (stride // 2).bit_length() - 1
+        dev = self.device
+        V_in = fine.V
+        ws_bytes = _lib.load().sv_stride_map_workspace_bytes(c_int64(V_in))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        keys = torch.empty(max(V_in, 1), dtype=torch.int64, device=dev)
+        coords = torch.empty((max(V_in, 1), 4), dtype=torch.int32, device=dev)
+        parent = torch.empty(max(V_in, 1), dtype=torch.int32, device=dev)
+        child_start = torch.empty(V_in + 1, dtype=torch.int32, device=dev)
+        counters = torch.empty(4, dtype=torch.int32, device=dev)
+        call("sv_stride_map", ptr(fine.keys), c_int64(V_in), c_int(level), ptr(ws), c_size_t(ws_bytes), ptr(keys),
+             ptr(coords), ptr(parent), ptr(child_start), ptr(counters), stream_ptr())
+        V = int(counters[0].item())
+        m = CoordinateMap(keys[:V], coords[:V], V, stride)
+        self.maps[stride] = m
+        self.parents[stride // 2] = (parent[:V_in], child_start[: V + 1])
+        return m
+
+    # ---- plans -----------------------------------------------------------------------------
+    def _build_plan(self, nbr, ld, mask, K, V_out):
+        dev = self.device
+        Vpad = _round_up(max(V_out, 1), SV_TILE_ROWS)
+        ws_bytes = _lib.load().sv_plan_workspace_bytes(c_int64(V_out))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        perm = torch.empty(Vpad, dtype=torch.int32, device=dev)
+        nbr_s = torch.empty((K, Vpad), dtype=torch.int32, device=dev)
+        submask = torch.empty((Vpad // SV_TILE_ROWS, K), dtype=torch.int32, device=dev)
+        call("sv_plan_build", ptr(nbr), c_int64(ld), ptr(mask), c_int(K), c_int64(V_out), ptr(ws), c_size_t(ws_bytes),
+             ptr(perm), ptr(nbr_s), ptr(submask), c_int64(Vpad), stream_ptr())
+        return ConvPlan(perm, nbr_s, submask, V_out, Vpad, K)
+
+    def plan_k3(self, stride, dilation=1):
+        key = ("k3", stride, dilation)
+        if key not in self.plans:
+            m = self.stride_map(stride)
+            tkeys, tvals, cap = m.hash()
+            V = m.V
+            nbr = torch.empty((27, max(V, 1)), dtype=torch.int32, device=self.device)
+            mask = torch.empty(max(V, 1), dtype=torch.int32, device=self.device)
+            call("sv_kernel_map_k3", ptr(m.coords), c_int64(V), c_int(stride), c_int(dilation), ptr(tkeys), ptr(tvals),
+                 c_int64(cap), ptr(nbr), c_int64(max(V, 1)), ptr(mask), stream_ptr())
+            self.plans[key] = self._build_plan(nbr, max(V, 1), mask, 27, V)
+        return self.plans[key]
+
+    def plan_down(self, stride):
+        """kernel_size 2, stride 2 convolution from tensor stride `stride` to 2*stride."""
+        key = ("down", stride)
+        if key not in self.plans:
+            fine = self.stride_map(stride)
+            coarse = self.stride_map(stride * 2)
+            parent, _ = self.parents[stride]
+            level = stride.bit_length() - 1
+            Vc = coarse.V
+            nbr = torch.empty((8, max(Vc, 1)), dtype=torch.int32, device=self.device)
+            mask = torch.empty(max(Vc, 1), dtype=torch.int32, device=self.device)
+            call("sv_kernel_map_down", ptr(fine.keys), ptr(parent), c_int64(fine.V), c_int(level), c_int64(Vc),
+                 ptr(nbr), c_int64(max(Vc, 1)), ptr(mask), stream_ptr())
+            self.plans[key] = self._build_plan(nbr, max(Vc, 1), mask, 8, Vc)
+        return self.plans[key]
+
+    def plan_up(self, stride):
+        """transposed kernel_size 2, stride 2 convolution from tensor stride `stride` to stride/2 (existing map)."""
+        key = ("up", stride)
+        if key not in self.plans:
+            fs = stride // 2
+            if fs not in self.maps or fs not in self.parents:
+                raise _lib.SvHipError(
+                    f"transposed conv to tensor stride {fs}: that coordinate map does not exist "
+                    "(ME semantics: the output reuses the encoder's map, model/backbone/minkunet.py:152-156)")
+            fine = self.maps[fs]
+            parent, _ = self.parents[fs]
+            level = fs.bit_length() - 1
+            V = fine.V
+            nbr = torch.empty((8, max(V, 1)), dtype=torch.int32, device=self.device)
+            mask = torch.empty(max(V, 1), dtype=torch.int32, device=self.device)
+            call("sv_kernel_map_up", ptr(fine.keys), ptr(parent), c_int64(V), c_int(level), ptr(nbr),
+                 c_int64(max(V, 1)), ptr(mask), stream_ptr())
+            self.plans[key] = self._build_plan(nbr, max(V, 1), mask, 8, V)
+        return self.plans[key]
+
+    def batch_offsets(self, stride, B):
+        key = (stride, B)
+        if key not in self._batch_offsets:
+            m = self.stride_map(stride)
+            bs = torch.empty(B + 1, dtype=torch.int32, device=self.device)
+            call("sv_batch_offsets", ptr(m.keys), c_int64(m.V), c_int(B), ptr(bs), stream_ptr())
+            self._batch_offsets[key] = bs
+        return self._batch_offsets[key]
+
+
+def _as_device(device):
+    if device is None:
+        device = "cuda"
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise _lib.SvHipError(
+            f"device {device}: the MI355X-native path runs on the GPU only (no CPU fallback by design)")
+    return device
+
+
+def _voxelize(coords, device, coords_are_int):
+    """Run sv_voxelize; returns (CoordinateMap at stride 1, inverse int64[N], order int32[N], seg_start int32[V+1])."""
+    N = coords.shape[0]
+    lib = _lib.load()
+    ws_bytes = lib.sv_voxelize_workspace_bytes(c_int64(N))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+    n1 = max(N, 1)
+    keys = torch.empty(n1, dtype=torch.int64, device=device)
+    vcoords = torch.empty((n1, 4), dtype=torch.int32, device=device)
+    inverse = torch.empty(n1, dtype=torch.int64, device=device)
+    order = torch.empty(n1, dtype=torch.int32, device=device)
+    seg_start = torch.empty(n1 + 1, dtype=torch.int32, device=device)
+    counters = torch.empty(4, dtype=torch.int32, device=device)
+    call("sv_voxelize", ptr(coords), c_int(1 if coords_are_int else 0), c_int64(N), ptr(ws), c_size_t(ws_bytes),
+         ptr(keys), ptr(vcoords), ptr(inverse), ptr(order), ptr(seg_start), ptr(counters), stream_ptr())
+    cnt = counters.tolist()
+    V, bad = cnt[0], cnt[1]
+    if bad:
+        raise _lib.SvHipError(
+            f"{bad} points have coordinates outside the key range (|coord| < 2^17 voxels, 0 <= batch < 1024)")
+    return CoordinateMap(keys[:V], vcoords[:V], V, 1), inverse[:N], order[:N], seg_start[: V + 1]
+
+
+def _voxel_reduce(feats, order, seg_start, V, mode):
+    C = feats.shape[1]
+    out = torch.empty((V, C), dtype=torch.float32, device=feats.device)
+    call("sv_voxel_reduce", ptr(feats), c_int(C), ptr(order), ptr(seg_start), c_int64(V), c_int(mode), ptr(out),
+         stream_ptr())
+    return out
+
+
+class TensorField:
+    """ME.TensorField: per-point features + continuous (pre-scaled) coordinates [N, 1+3] = (batch, x, y, z)."""
+
+    def __init__(self, features, coordinates=None, quantization_mode=SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE,
+                 minkowski_algorithm=MinkowskiAlgorithm.DEFAULT, device=None, coordinate_manager=None,
+                 inverse_mapping=None):
+        device = _as_device(device if device is not None else (features.device if features.is_cuda else None))
+        self.device = device
+        self._F = features.to(device=device, dtype=torch.float32).contiguous()
+        self.quantization_mode = quantization_mode
+        self.minkowski_algorithm = minkowski_algorithm
+        self.coordinate_manager = coordinate_manager
+        self.inverse_mapping = inverse_mapping
+        if coordinates is not None:
+            if coordinates.shape[0] != features.shape[0] or coordinates.shape[1] != 4:
+                raise ValueError("coordinates must be [N, 4] = (batch, x, y, z) with one row per feature row")
+            self._C = coordinates.to(device=device, dtype=torch.float32).contiguous()
+        else:
+            self._C = None
+        self._order = None
+        self._seg_start = None
+
+    @property
+    def F(self):
+        return self._F
+
+    features = F
+
+    @property
+    def C(self):
+        return self._C
+
+    coordinates = C
+
+    def __len__(self):
+        return self._F.shape[0]
+
+    def sparse(self):
+        """Voxelise: floor the coordinates, unique voxels in canonical order, per-voxel feature mean."""
+        if self._C is None:
+            raise ValueError("TensorField has no coordinates")
+        if self.quantization_mode not in (SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE,
+                                          SparseTensorQuantizationMode.RANDOM_SUBSAMPLE):
+            raise NotImplementedError(f"quantization_mode {self.quantization_mode}")
+        cmap, inverse, order, seg_start = _voxelize(self._C, self.device, coords_are_int=False)
+        cm = CoordinateManager(self.device)
+        cm.maps[1] = cmap
+        self.coordinate_manager = cm
+        self.inverse_mapping = inverse
+        self._order, self._seg_start = order, seg_start
+        mode = (_lib.SV_REDUCE_MEAN if self.quantization_mode == SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE
+                else _lib.SV_REDUCE_FIRST)
+        feats = _voxel_reduce(self._F, order, seg_start, cmap.V, mode)
+        return SparseTensor(feats, coordinate_manager=cm, tensor_stride=1, _internal=True)
+
+
+class SparseTensor:
+    """ME.SparseTensor: features [V, C] on a coordinate map of a CoordinateManager."""
+
+    def __init__(self, features, coordinates=None, tensor_stride=1, coordinate_manager=None, device=None,
+                 quantization_mode=SparseTensorQuantizationMode.RANDOM_SUBSAMPLE, requires_grad=False,
+                 _internal=False):
+        if _internal:
+            self._F = features
+            self.coordinate_manager = coordinate_manager
+            self.tensor_stride = tensor_stride
+            self.device = features.device
+            self.inverse_mapping = None
+            return
+        device = _as_device(device if device is not None else (features.device if features.is_cuda else None))
+        self.device = device
+        if coordinates is None:
+            if coordinate_manager is None:
+                raise ValueError("either coordinates or a coordinate_manager is required")
+            self._F = features.to(device=device, dtype=torch.float32).contiguous()
+            self.coordinate_manager = coordinate_manager
+            self.tensor_stride = tensor_stride
+            self.inverse_mapping = None
+            return
+        # ME.SparseTensor(feats, coordinates=int coords [N,4]) — train_segmentation.py:78: already-quantised rows
+        coords = coordinates.to(device=device, dtype=torch.int32).contiguous()
+        feats = features.to(device=device, dtype=torch.float32).contiguous()
+        if coords.shape[0] != feats.shape[0] or coords.shape[1] != 4:
+            raise ValueError("coordinates must be [N, 4] = (batch, x, y, z) with one row per feature row")
+        cmap, inverse, order, seg_start = _voxelize(coords, device, coords_are_int=True)
+        cm = CoordinateManager(device)
+        cm.maps[1] = cmap
+        mode = (_lib.SV_REDUCE_MEAN if quantization_mode == SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE
+                else _lib.SV_REDUCE_FIRST)
+        self._F = _voxel_reduce(feats, order, seg_start, cmap.V, mode)
+        self.coordinate_manager = cm
+        self.tensor_stride = 1
+        self.inverse_mapping = inverse
+
+    # ---- ME accessors ----------------------------------------------------------------------
+    @property
+    def F(self):
+        return self._F
+
+    features = F
+
+    @property
+    def coordinate_map(self):
+        return self.coordinate_manager.stride_map(self.tensor_stride)
+
+    @property
+    def C(self):
+        return self.coordinate_map.coords
+
+    coordinates = C
+
+    @property
+    def shape(self):
+        return self._F.shape
+
+    def __len__(self):
+        return self._F.shape[0]
+
+    @property
+    def decomposed_coordinates(self):
+        m = self.coordinate_map
+        B = int(m.coords[:, 0].max().item()) + 1 if m.V else 0
+        bs = self.coordinate_manager.batch_offsets(self.tensor_stride, max(B, 1)).tolist()
+        return [m.coords[bs[b]: bs[b + 1], 1:] for b in range(B)]
+
+    @property
+    def decomposed_features(self):
+        m = self.coordinate_map
+        B = int(m.coords[:, 0].max().item()) + 1 if m.V else 0
+        bs = self.coordinate_manager.batch_offsets(self.tensor_stride, max(B, 1)).tolist()
+        return [self._F[bs[b]: bs[b + 1]] for b in range(B)]
+
+    def new(self, features, tensor_stride=None):
+        return SparseTensor(features, coordinate_manager=self.coordinate_manager,
+                            tensor_stride=self.tensor_stride if tensor_stride is None else tensor_stride,
+                            _internal=True)
+
+    def slice(self, field):
+        """Voxel -> point broadcast: TensorField whose rows are this tensor's rows at field.inverse_mapping."""
+        if self.tensor_stride != 1:
+            raise ValueError("slice needs a tensor at tensor stride 1")
+        inv = field.inverse_mapping
+        if inv is None or field.coordinate_manager is not self.coordinate_manager:
+            raise ValueError("the field was not voxelised into this tensor's coordinate manager")
+        N, C = inv.shape[0], self._F.shape[1]
+        out = torch.empty((N, C), dtype=torch.float32, device=self._F.device)
+        call("sv_slice_rows", ptr(self._F), c_int64(self._F.stride(0)), c_int(C), ptr(inv), c_int64(N), ptr(out),
+             stream_ptr())
+        return TensorField(out, coordinates=None, device=self._F.device, coordinate_manager=self.coordinate_manager,
+                           inverse_mapping=inv)
+
+    def slice_argmax(self, field, with_conf=True):
+        """Fused slice + utils/output.py:67-73: per-point label (first row maximum) and sigmoid(max)."""
+        inv = field.inverse_mapping
+        if inv is None or field.coordinate_manager is not self.coordinate_manager:
+            raise ValueError("the field was not voxelised into this tensor's coordinate manager")
+        N, C = inv.shape[0], self._F.shape[1]
+        label = torch.empty(N, dtype=torch.int64, device=self._F.device)
+        conf = torch.empty(N, dtype=torch.float32, device=self._F.device) if with_conf else None
+        call("sv_slice_argmax", ptr(self._F), c_int64(self._F.stride(0)), c_int(C), ptr(inv), c_int64(N), ptr(label),
+             ptr(conf), stream_ptr())
+        return label, conf
+
+    # dense [B, C] results of global pooling are plain tensors in this build; `out[0][3:]` works on them directly
+
+
+def cat(*tensors):
+    """ME.cat: channel concatenation of tensors on the same coordinate map (model/backbone/minkunet.py:156)."""
+    if len(tensors) == 1 and isinstance(tensors[0], (list, tuple)):
+        tensors = tuple(tensors[0])
+    first = tensors[0]
+    for t in tensors[1:]:
+        if t.coordinate_manager is not first.coordinate_manager or t.tensor_stride != first.tensor_stride:
+            raise ValueError("ME.cat needs tensors on the same coordinate map")
+    return first.new(torch.cat([t.F for t in tensors], dim=1))

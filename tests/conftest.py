@@ -1,0 +1,45 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import sv_oracle
+
+    sv_oracle.lib()
+    return sv_oracle
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+
+    def load(name):
+        return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+    return load
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """cuda:0 device; fails (not skips) when a gpu-marked test runs without the HIP library or a GPU."""
+    import torch
+
+    import mrcc_amd
+
+    mrcc_amd._lib.load()
+    assert torch.cuda.is_available(), "gpu-marked test needs a GPU"
+    return torch.device("cuda:0")

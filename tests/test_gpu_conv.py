@@ -1,0 +1,107 @@
+"""A3/A5 parity: the fp32-MFMA sparse convolution vs the C oracle's fmaf chain — BIT-EXACT (same accumulation order)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(gpu, n=20000, L=1.0, scale=50, seed=0, batch=1):
+    import mrcc_amd
+    from mrcc_amd import MinkowskiEngine as ME
+
+    parts, bcol = [], []
+    for b in range(batch):
+        p, _, _ = mrcc_amd.synth.gen_room(n, L, seed + b)
+        parts.append(p - np.float32(L))
+        bcol.append(np.full((len(p), 1), b, np.float32))
+    pts = np.concatenate(parts)
+    coords4 = np.concatenate([np.concatenate(bcol), pts * np.float32(scale)], axis=1)
+    rgb = np.random.default_rng(seed).uniform(-0.5, 0.5, size=(len(pts), 3)).astype(np.float32)
+    field = ME.TensorField(torch.from_numpy(rgb), torch.from_numpy(coords4), device=gpu)
+    return ME, field, field.sparse(), coords4
+
+
+def _same(a, b):
+    """bitwise equality up to the sign of zero (a skipped neighbour is fma(0, w, acc) on the GPU)."""
+    return np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("cin,cout", [(3, 32), (32, 32), (32, 64), (64, 128), (96, 384), (416, 384), (7, 5),
+                                      (130, 200)])
+def test_conv_k3_bit_exact(gpu, oracle, cin, cout):
+    from mrcc_amd import nn as svnn
+
+    ME, field, st, coords4 = _setup(gpu, n=12000, L=0.8)
+    frame = oracle.Frame(oracle.voxelize(coords4)["coords"])
+    V = st.F.shape[0]
+    rng = np.random.default_rng(cin * 1000 + cout)
+    x = rng.normal(size=(V, cin)).astype(np.float32)
+    W = (rng.normal(size=(27, cin, cout)) * np.sqrt(2.0 / (27 * cout))).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, size=cout).astype(np.float32)
+    shift = rng.normal(size=cout).astype(np.float32)
+    res = rng.normal(size=(V, cout)).astype(np.float32)
+    plan = st.coordinate_manager.plan_k3(1)
+    t = lambda a: torch.from_numpy(a).to(gpu)
+    # plain conv
+    got = svnn.conv_forward(t(x), t(W), plan, V).cpu().numpy()
+    want = oracle.conv(x, W, frame.k3(1), V)
+    assert _same(got, want), f"max abs diff {np.abs(got - want).max()}"
+    # fused BN + residual + ReLU
+    got = svnn.conv_forward(t(x), t(W), plan, V, t(scale), t(shift), t(res), 1).cpu().numpy()
+    want = oracle.conv(x, W, frame.k3(1), V, scale, shift, res, oracle.ACT_RELU)
+    assert _same(got, want), f"max abs diff {np.abs(got - want).max()}"
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 32), (128, 128), (256, 384), (384, 384)])
+def test_conv_down_up_bit_exact(gpu, oracle, cin, cout):
+    from mrcc_amd import nn as svnn
+
+    ME, field, st, coords4 = _setup(gpu, n=15000, L=0.8, batch=2)
+    cm = st.coordinate_manager
+    frame = oracle.Frame(oracle.voxelize(coords4)["coords"])
+    rng = np.random.default_rng(7)
+    t = lambda a: torch.from_numpy(a).to(gpu)
+    for ts in (1, 2):
+        Vf, Vc = len(frame.maps[ts]), len(frame.down(ts))
+        W = (rng.normal(size=(8, cin, cout)) * 0.1).astype(np.float32)
+        xf = rng.normal(size=(Vf, cin)).astype(np.float32)
+        got = svnn.conv_forward(t(xf), t(W), cm.plan_down(ts), Vc, act=1).cpu().numpy()
+        want = oracle.conv(xf, W, frame.kdown(ts), Vc, act=oracle.ACT_RELU)
+        assert _same(got, want)
+        xc = rng.normal(size=(Vc, cin)).astype(np.float32)
+        got = svnn.conv_forward(t(xc), t(W), cm.plan_up(2 * ts), Vf).cpu().numpy()
+        want = oracle.conv(xc, W, frame.kup(2 * ts), Vf)
+        assert _same(got, want)
+
+
+@pytest.mark.parametrize("V,cin,cout", [(1, 4, 4), (127, 256, 1024), (129, 1024, 3), (5000, 384, 256), (300, 9, 7),
+                                        (64, 2048, 7)])
+def test_dense_linear_bit_exact(gpu, oracle, V, cin, cout):
+    from mrcc_amd import nn as svnn
+
+    rng = np.random.default_rng(V + cin + cout)
+    x = rng.normal(size=(V, cin)).astype(np.float32)
+    W = (rng.normal(size=(1, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    bias = rng.normal(size=cout).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(gpu)
+    got = svnn.conv_forward(t(x), t(W), None, V, None, t(bias), None, 2, 0.01).cpu().numpy()
+    want = oracle.conv(x, W, None, V, None, bias, None, oracle.ACT_LEAKY, 0.01)
+    assert _same(got, want), f"max abs diff {np.abs(got - want).max()}"
+
+
+def test_strided_input_and_affine(gpu, oracle):
+    """row strides (ld) != channel count: a column slice of a wider buffer as conv input."""
+    from mrcc_amd import nn as svnn
+
+    rng = np.random.default_rng(0)
+    V = 1000
+    big = rng.normal(size=(V, 96)).astype(np.float32)
+    W = rng.normal(size=(1, 64, 48)).astype(np.float32)
+    tb = torch.from_numpy(big).to(gpu)
+    got = svnn.conv_forward(tb[:, 32:], torch.from_numpy(W).to(gpu), None, V).cpu().numpy()
+    assert _same(got, oracle.conv(big[:, 32:], W, None, V))
+    s = rng.uniform(0.5, 2, size=96).astype(np.float32)
+    b = rng.normal(size=96).astype(np.float32)
+    got = svnn.affine_act(tb, torch.from_numpy(s).to(gpu), torch.from_numpy(b).to(gpu), act=2, slope=0.01)
+    assert _same(got.cpu().numpy(), oracle.affine_act(big, s, b, None, oracle.ACT_LEAKY, 0.01))

@@ -1,0 +1,126 @@
+"""A1/A2 parity: HIP voxelisation / coordinate maps / kernel maps vs the CPU oracle — bit-exact (integer work)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _field(ME, pts, rgb, scale, dev, batch=None):
+    b = np.zeros((len(pts), 1), np.float32) if batch is None else batch.reshape(-1, 1).astype(np.float32)
+    coords = torch.from_numpy(np.concatenate([b, pts * np.float32(scale)], axis=1))
+    return ME.TensorField(features=torch.from_numpy(rgb), coordinates=coords,
+                          quantization_mode=ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE,
+                          minkowski_algorithm=ME.MinkowskiAlgorithm.SPEED_OPTIMIZED, device=dev), coords.numpy()
+
+
+@pytest.mark.parametrize("n,L,scale,seed", [(20000, 1.0, 50, 0), (80000, 1.5, 50, 1), (5000, 0.5, 200, 2)])
+def test_voxelize_matches_oracle(gpu, oracle, n, L, scale, seed):
+    import mrcc_amd
+    from mrcc_amd import MinkowskiEngine as ME
+
+    pts, rgb, _ = mrcc_amd.synth.gen_room(n, L, seed)
+    pts[: n // 2] -= np.float32(L)  # negative coordinates exercise floor toward -inf
+    field, coords4 = _field(ME, pts, rgb, scale, gpu)
+    st = field.sparse()
+    ref = oracle.voxelize(coords4)
+    cmap = st.coordinate_map
+    assert cmap.V == len(ref["keys"])
+    assert np.array_equal(cmap.keys.cpu().numpy().view(np.uint64), ref["keys"])
+    assert np.array_equal(cmap.coords.cpu().numpy(), ref["coords"])
+    assert np.array_equal(field.inverse_mapping.cpu().numpy(), ref["inverse"])
+    feats = oracle.voxel_reduce(rgb, ref["order"], ref["seg_start"], 0)
+    assert np.array_equal(st.F.cpu().numpy(), feats)  # sequential mean in point order: bit-exact
+
+
+def test_voxelize_batched_and_int_coords(gpu, oracle):
+    import mrcc_amd
+    from mrcc_amd import MinkowskiEngine as ME
+
+    rng = np.random.default_rng(3)
+    parts, batch = [], []
+    for b in range(5):
+        p, _, _ = mrcc_amd.synth.gen_room(3000 + 500 * b, 0.8, 10 + b)
+        parts.append(p)
+        batch.append(np.full(len(p), b))
+    pts, batch = np.concatenate(parts), np.concatenate(batch)
+    rgb = rng.uniform(-0.5, 0.5, size=(len(pts), 3)).astype(np.float32)
+    perm = rng.permutation(len(pts))  # interleave the frames: rows must still come out batch-major
+    pts, batch, rgb = pts[perm], batch[perm], rgb[perm]
+    field, coords4 = _field(ME, pts, rgb, 50, gpu, batch)
+    st = field.sparse()
+    ref = oracle.voxelize(coords4)
+    assert np.array_equal(st.C.cpu().numpy(), ref["coords"])
+    assert np.all(np.diff(ref["coords"][:, 0]) >= 0)
+    # ME.SparseTensor(feats, coordinates=int coords) path (train_segmentation.py:78)
+    ic = np.concatenate([batch.reshape(-1, 1), np.floor(pts * 50)], axis=1).astype(np.int32)
+    st2 = ME.SparseTensor(torch.from_numpy(rgb), coordinates=torch.from_numpy(ic), device=gpu)
+    ref2 = oracle.voxelize(ic, coords_are_int=True)
+    assert np.array_equal(st2.C.cpu().numpy(), ref2["coords"])
+    assert np.array_equal(st2.F.cpu().numpy(), oracle.voxel_reduce(rgb, ref2["order"], ref2["seg_start"], 1))
+    dc = st.decomposed_coordinates
+    assert len(dc) == 5 and sum(len(d) for d in dc) == len(ref["coords"])
+
+
+def test_voxelize_edge_cases(gpu, oracle):
+    import mrcc_amd
+    from mrcc_amd import MinkowskiEngine as ME
+
+    # single point, duplicated points, and out-of-range coordinates must be reported, not wrapped
+    one = np.array([[0.013, -0.002, 0.4]], np.float32)
+    field, c4 = _field(ME, one, np.ones((1, 3), np.float32), 50, gpu)
+    st = field.sparse()
+    assert st.F.shape == (1, 3) and np.array_equal(st.C.cpu().numpy(), oracle.voxelize(c4)["coords"])
+    dup = np.repeat(one, 1000, axis=0)
+    f = np.arange(3000, dtype=np.float32).reshape(1000, 3)
+    field, c4 = _field(ME, dup, f, 50, gpu)
+    st = field.sparse()
+    ref = oracle.voxelize(c4)
+    assert st.F.shape == (1, 3)
+    assert np.array_equal(st.F.cpu().numpy(), oracle.voxel_reduce(f, ref["order"], ref["seg_start"], 0))
+    far = np.array([[1e6, 0, 0]], np.float32)
+    field, _ = _field(ME, far, np.ones((1, 3), np.float32), 50, gpu)
+    with pytest.raises(mrcc_amd._lib.SvHipError):
+        field.sparse()
+
+
+@pytest.mark.parametrize("n,L,scale", [(30000, 1.0, 50), (8000, 0.4, 200)])
+def test_stride_and_kernel_maps_match_oracle(gpu, oracle, n, L, scale):
+    import mrcc_amd
+    from mrcc_amd import MinkowskiEngine as ME
+
+    pts, rgb, _ = mrcc_amd.synth.gen_room(n, L, 5)
+    pts -= np.float32(L)  # straddle zero
+    field, coords4 = _field(ME, pts, rgb, scale, gpu)
+    st = field.sparse()
+    cm = st.coordinate_manager
+    frame = oracle.Frame(oracle.voxelize(coords4)["coords"])
+    for level in range(4):
+        ts = 2 ** level
+        coarse = frame.down(ts)
+        m = cm.stride_map(2 * ts)
+        assert np.array_equal(m.coords.cpu().numpy(), coarse)
+        parent, child_start = cm.parents[ts]
+        assert np.array_equal(parent.cpu().numpy().astype(np.int64), frame.parent[ts])
+        cs = child_start.cpu().numpy()
+        assert cs[0] == 0 and cs[-1] == len(frame.maps[ts]) and np.all(np.diff(cs) >= 1)
+
+    def unsort(plan):
+        """Undo the mask sort: nbr in canonical output-row order."""
+        perm = plan.perm.cpu().numpy()
+        nbr_s = plan.nbr_s.cpu().numpy()
+        valid = perm >= 0
+        assert valid.sum() == plan.V_out and np.array_equal(np.sort(perm[valid]), np.arange(plan.V_out))
+        out = np.full((plan.K, plan.V_out), -2, np.int32)
+        out[:, perm[valid]] = nbr_s[:, valid]
+        assert np.all(nbr_s[:, ~valid] == -1)
+        # submask bit s of tile t for offset k <=> some row of that 16-row sub-tile has a neighbour at k
+        sub = (nbr_s >= 0).reshape(plan.K, plan.Vpad // 128, 8, 16).any(axis=3)  # [K, tiles, 8]
+        bits = (sub * (1 << np.arange(8))).sum(axis=2).T  # [tiles, K]
+        assert np.array_equal(plan.submask.cpu().numpy().astype(np.int64), bits)
+        return out
+
+    for ts in (1, 2, 4):
+        assert np.array_equal(unsort(cm.plan_k3(ts)), frame.k3(ts))
+        assert np.array_equal(unsort(cm.plan_down(ts)), frame.kdown(ts))
+        assert np.array_equal(unsort(cm.plan_up(2 * ts)), frame.kup(2 * ts))

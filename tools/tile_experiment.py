@@ -1,0 +1,70 @@
+"""CPU experiment: MFMA-tile efficiency of output-stationary sparse conv under different row orders."""
+import sys, importlib.util, numpy as np
+sys.path.insert(0, ".")
+spec = importlib.util.spec_from_file_location("synth", "markerless-robot-camera-calibration_amd/synth.py")
+synth = importlib.util.module_from_spec(spec); spec.loader.exec_module(synth)
+
+def morton3(x, y, z, bits=18):
+    out = np.zeros_like(x, dtype=np.uint64)
+    for b in range(bits):
+        out |= ((x >> b) & 1).astype(np.uint64) << np.uint64(3 * b)
+        out |= ((y >> b) & 1).astype(np.uint64) << np.uint64(3 * b + 1)
+        out |= ((z >> b) & 1).astype(np.uint64) << np.uint64(3 * b + 2)
+    return out
+
+def level_stats(c, ts, name):
+    # c: unique int coords [V,3] (multiples of ts)
+    V = len(c)
+    bias = 1 << 17
+    key = morton3(*(c.T.astype(np.int64) + bias))
+    order = np.argsort(key); c = c[order]; key = key[order]
+    lut = {k: i for i, k in enumerate(key.tolist())}
+    nbr = np.full((27, V), -1, dtype=np.int64)
+    ki = 0
+    for dz in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                q = c + np.array([dx, dy, dz]) * ts
+                kq = morton3(*(q.T.astype(np.int64) + bias))
+                # vectorised lookup via searchsorted
+                pos = np.searchsorted(key, kq)
+                pos[pos >= V] = V - 1
+                hit = key[pos] == kq
+                nbr[ki, hit] = pos[hit]
+                ki += 1
+    act = nbr >= 0
+    P = act.sum()
+    mask = np.zeros(V, dtype=np.int64)
+    for k in range(27):
+        mask |= act[k].astype(np.int64) << k
+    print(f"{name}: V={V} pairs={P} avg nbr={P/V:.2f} distinct masks={len(np.unique(mask))}")
+    def eff(perm, g):
+        a = act[:, perm]
+        pad = (-V) % g
+        if pad:
+            a = np.concatenate([a, np.zeros((27, pad), bool)], axis=1)
+        t = a.reshape(27, -1, g).any(axis=2)
+        return P / (t.sum() * g)
+    ident = np.arange(V)
+    bymask = np.argsort(mask, kind="stable")
+    # sort with bit-significance by closeness to p=0.5
+    p = act.mean(axis=1)
+    bitorder = np.argsort(np.abs(p - 0.5))  # most uncertain first => most significant
+    m2 = np.zeros(V, dtype=np.int64)
+    for rank, k in enumerate(bitorder):
+        m2 |= act[k].astype(np.int64) << (26 - rank)
+    bym2 = np.argsort(m2, kind="stable")
+    # popcount-then-mask
+    for g in (16, 32, 64, 128):
+        print(f"   g={g:4d}: morton {eff(ident,g):.3f}  mask-sort {eff(bymask,g):.3f}  entropy-bit-sort {eff(bym2,g):.3f}")
+    return c
+
+n, L, scale = 200000, 2.4, 50
+pts, rgb, lab = synth.gen_room(n, L, 0)
+c0 = np.unique(np.floor(pts * scale).astype(np.int64), axis=0)
+ts = 1
+c = c0
+for lvl in range(5):
+    level_stats(c, ts, f"level{lvl} ts={ts}")
+    ts *= 2
+    c = np.unique((c // ts) * ts, axis=0)
