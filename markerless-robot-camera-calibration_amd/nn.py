@@ -11,6 +11,7 @@ single hook for adapting a real ME checkpoint if its order turns out to differ (
 import math
 from ctypes import c_float, c_int, c_int64
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -75,15 +76,17 @@ def global_pool(x, mode):
 
 def fold_bn(bn):
     """BatchNorm1d(eval) as y = fmaf(x, scale, shift): scale = w / sqrt(var + eps), shift = b - mean * scale.
-    Computed in float32 on the host with exactly the operations oracle/sv_oracle.py:fold_bn uses."""
-    w = bn.weight.detach().float().cpu() if bn.weight is not None else torch.ones(bn.num_features)
-    b = bn.bias.detach().float().cpu() if bn.bias is not None else torch.zeros(bn.num_features)
-    mean = bn.running_mean.detach().float().cpu()
-    var = bn.running_var.detach().float().cpu()
-    scale = w / torch.sqrt(var + torch.tensor(bn.eps, dtype=torch.float32))
-    shift = b - mean * scale
+    Host-side, once per model, in numpy float32 (correctly rounded IEEE sqrt / divide; torch's vectorised CPU path
+    is 1 ulp off), i.e. exactly the arithmetic oracle/sv_oracle.py:fold_bn defines."""
+    n = bn.num_features
+    w = bn.weight.detach().float().cpu().numpy() if bn.weight is not None else np.ones(n, np.float32)
+    b = bn.bias.detach().float().cpu().numpy() if bn.bias is not None else np.zeros(n, np.float32)
+    mean = bn.running_mean.detach().float().cpu().numpy()
+    var = bn.running_var.detach().float().cpu().numpy()
+    scale = (w / np.sqrt(var + np.float32(bn.eps))).astype(np.float32)
+    shift = (b - mean * scale).astype(np.float32)
     dev = bn.running_mean.device
-    return scale.to(dev).contiguous(), shift.to(dev).contiguous()
+    return torch.from_numpy(scale).to(dev), torch.from_numpy(shift).to(dev)
 
 
 def _tensor_versions(*ts):
