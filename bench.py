@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py — headline metric of BASELINE.json: point-cloud frames/sec at 200k pts/frame on N MI355X.
+
+A step = one pass of the hot path over one synthetic frame that is already resident in HBM:
+    voxelise (floor, sort, unique, mean) -> coordinate maps + kernel maps + conv plans -> RobotNetSegmentation
+    (MinkUNet18D, fp32 MFMA, fused BN/ReLU/residual) -> fused slice + argmax -> per-point labels.
+Every step sees a different frame object; nothing (coordinate maps, plans, outputs) is cached across steps.
+
+N > 1: frames shard across ranks (one process per GPU, launched by torch.distributed.run); there is no data-path
+collective — one RCCL all_gather of a small metrics record at the end.  value = frames processed by
+all ranks / max-over-ranks wall time.
+
+Also in the JSON line: `roofline` for the dominant kernel (live HIP-event timing of every sv_conv_fwd launch in the
+timed region) and, at N = 1, `cpu_baseline` = the C oracle (oracle/sv_oracle.c, OpenMP) timed on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import mrcc_amd  # noqa: E402
+from mrcc_amd import MinkowskiEngine as ME  # noqa: E402
+from mrcc_amd import profiling  # noqa: E402
+
+POINTS = 200_000
+ROOM = 2.4
+SCALE = 50  # 2 cm voxels
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32 matrix peak
+PEAK_HBM_GBS = 8000.0
+
+
+def build_model(device):
+    from mrcc_amd.model.robotnet_segmentation import RobotNetSegmentation
+
+    torch.manual_seed(1)
+    model = RobotNetSegmentation(in_channels=3, num_classes=3)
+    return model.to(device).eval()
+
+
+def make_frame(seed, device, n=POINTS, L=ROOM):
+    pts, rgb, lab = mrcc_amd.synth.gen_room(n, L, seed)
+    coords4 = np.concatenate([np.zeros((n, 1), np.float32), pts * np.float32(SCALE)], axis=1)
+    return (torch.from_numpy(coords4).to(device), torch.from_numpy(rgb).to(device), pts, rgb, lab)
+
+
+def run_frame(model, coords4, rgb):
+    field = ME.TensorField(features=rgb, coordinates=coords4,
+                           quantization_mode=ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE,
+                           minkowski_algorithm=ME.MinkowskiAlgorithm.SPEED_OPTIMIZED, device=rgb.device)
+    x = field.sparse()
+    out = model(x)
+    label, conf = out.slice_argmax(field)
+    return label, x.F.shape[0]
+
+
+def cpu_baseline(model, budget_s=25.0):
+    """Time the oracle (C restatement, OpenMP over output rows) on the host cores.  Bounded: a quarter-size frame
+    first; the full 200k-point frame only if the estimate says it fits the budget."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import sv_oracle as O
+
+    cores = len(os.sched_getaffinity(0))
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    sd = {k: v.cpu() for k, v in model.state_dict().items()}
+    pts, rgb, _ = mrcc_amd.synth.gen_room(POINTS // 4, ROOM / 2, 0)
+    t0 = time.perf_counter()
+    r = O.predict_segmentation(sd, pts, rgb, SCALE)
+    t_small = time.perf_counter() - t0
+    v_small = len(r["vox"]["keys"])
+    est_full = t_small * 4.0
+    if est_full <= budget_s:
+        pts, rgb, _ = mrcc_amd.synth.gen_room(POINTS, ROOM, 0)
+        t0 = time.perf_counter()
+        r = O.predict_segmentation(sd, pts, rgb, SCALE)
+        t_full = time.perf_counter() - t0
+        return {"value": 1.0 / t_full, "unit": "frames/s", "cores": O.lib().or_num_threads(), "kind": "port",
+                "sample": f"1 full frame: {POINTS} pts, {len(r['vox']['keys'])} voxels, {t_full:.2f} s "
+                          f"(C oracle, OpenMP, fp32 fmaf chain; quarter frame took {t_small:.2f} s)"}
+    return {"value": 1.0 / est_full, "unit": "frames/s", "cores": O.lib().or_num_threads(), "kind": "port",
+            "sample": f"quarter-size frame ({POINTS // 4} pts, L={ROOM / 2} m, {v_small} voxels) took {t_small:.2f} s; "
+                      f"value = 1 / (4 x that): work is linear in voxels"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pool", type=int, default=4, help="distinct frames resident per rank")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    mrcc_amd._lib.load()
+
+    model = build_model(device)
+    # rank r owns frames r, r + world, ... of the global seed sequence (Cfg-4 sharding rule)
+    frames = [make_frame(rank + world * i, device) for i in range(args.pool)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    with torch.no_grad():
+        for i in range(args.warmup):
+            run_frame(model, *frames[i % args.pool][:2])
+        timer = profiling.KernelTimer()
+        profiling.TIMER = timer
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        hist = torch.zeros(3, dtype=torch.int64, device=device)
+        voxels = 0
+        for i in range(args.steps):
+            label, V = run_frame(model, *frames[i % args.pool][:2])
+            hist += torch.bincount(label, minlength=3)
+            voxels += V
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        profiling.TIMER = None
+
+    # one collective: per-rank record {elapsed, frames, voxels, label histogram}
+    rec = torch.tensor([elapsed, float(args.steps), float(voxels)] + hist.double().tolist(), dtype=torch.float64,
+                       device=device)
+    if world > 1:
+        allrec = [torch.zeros_like(rec) for _ in range(world)]
+        dist.all_gather(allrec, rec)
+        allrec = torch.stack(allrec).cpu().numpy()
+    else:
+        allrec = rec.cpu().numpy()[None]
+    t_max = float(allrec[:, 0].max())
+    total_frames = float(allrec[:, 1].sum())
+
+    if rank == 0:
+        ksum = timer.summarize()
+        dom = max(ksum.items(), key=lambda kv: kv[1]["ms"]) if ksum else None
+        roofline = None
+        if dom is not None:
+            name, d = dom
+            tflops = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            roofline = {
+                "kernel": name, "bound": "mfma", "achieved": round(tflops, 3), "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+                "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
+                "share_of_step_time": round(d["ms"] / (elapsed * 1e3), 4),
+            }
+        kernels = {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),
+                       "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                       "gather_GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for k, v in ksum.items()}
+        line = {
+            "metric": "point-cloud frames/sec at 200k pts/frame", "value": round(total_frames / t_max, 3),
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(t_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg2: synthetic 200k-pt RGB-D cloud, 2 cm voxels, RobotNetSegmentation(MinkUNet18D) "
+                                   "forward = voxelise + sparse U-Net + slice/argmax, random-init weights",
+                       "points_per_frame": POINTS, "voxel_size_m": 1.0 / SCALE,
+                       "active_voxels_per_frame": int(allrec[0, 2] / allrec[0, 1]),
+                       "parallelism": f"frame-sharded x{world}, one RCCL all_gather of metrics"},
+            "roofline": roofline,
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(model)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -41,6 +41,8 @@ struct ConvParams {
   int64_t out_ld;
   int vec_a;  // in_ld % 4 == 0 && Cin % 4 == 0 && base aligned -> float4 gathers
   int vec_b;  // Cout % 4 == 0 && W aligned -> float4 weight loads
+  int ntiles;
+  int ny;
 };
 
 constexpr int TM = SV_TILE_ROWS;  // 128 rows per tile
@@ -53,25 +55,33 @@ struct ConvCfg {
   static constexpr int MR = (TM / WAVES_M) / 16;  // 16-row sub-tiles per wave
   static constexpr int TN = WAVES_N * NT * 16;    // output channels per workgroup
   static constexpr int SB = TN + 16;              // B row stride in floats (== 16 mod 32)
-  static constexpr size_t LDS_BYTES = (size_t)(TM * SA + KC * SB) * sizeof(float);
+  static constexpr int B_F4 = (KC * TN / 4 + 255) / 256;  // float4 weight loads per thread and step
+  static constexpr size_t lds_bytes(int K) { return (size_t)(TM * SA + KC * SB + K * TM) * sizeof(float); }
 };
 
+// One pipeline step = (kernel offset k, input-channel chunk c0).  A step's global loads are issued into registers
+// BEFORE the previous step's MFMAs and written to LDS after them, so HBM/L2 latency hides under matrix work.
 template <int WAVES_N, int NT>
-__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvParams p) {
+__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
   using Cfg = ConvCfg<WAVES_N, NT>;
-  constexpr int MR = Cfg::MR, TN = Cfg::TN, SB = Cfg::SB, WAVES_M = Cfg::WAVES_M;
+  constexpr int MR = Cfg::MR, TN = Cfg::TN, SB = Cfg::SB, B_F4 = Cfg::B_F4;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* As = lds;             // [TM][SA]
-  float* Bs = lds + TM * SA;   // [KC][SB]
+  float* As = lds;                              // [TM][SA]
+  float* Bs = lds + TM * SA;                    // [KC][SB]
+  int* idx_s = (int*)(lds + TM * SA + KC * SB);  // [K][TM] gathered input row of every (offset, tile row)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
-  const int tile = blockIdx.x;
-  const int n0 = blockIdx.y * TN;
+  // 1-D grid, heavy tiles first: rows are mask-sorted ascending, so the tiles with the most neighbour offsets sit at the
+  // end of the plan; dispatching them first keeps the tail of the launch short (list scheduling, longest first).
+  const int ny = p.ny;
+  const int tile = p.ntiles - 1 - (int)(blockIdx.x / ny);
+  const int n0 = (int)(blockIdx.x % ny) * TN;
   const int64_t row0 = (int64_t)tile * TM;
   const int li = lane & 15, lq = lane >> 4;
+  const int K = p.K, Cin = p.Cin, Cout = p.Cout;
 
   f32x4 acc[MR][NT];
 #pragma unroll
@@ -79,106 +89,163 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvParams p) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[s][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // dense tail tile: which 16-row sub-tiles exist at all
+  // ---- stage the tile's neighbour table (or the identity for dense rows) in LDS
   uint32_t dense_mask = 0xffu;
   if (p.submask == nullptr) {
-    int64_t rem = p.V_out - row0;
-    int nsub = rem >= TM ? 8 : (int)((rem + 15) / 16);
+    const int64_t rem = p.V_out - row0;
+    const int nsub = rem >= TM ? 8 : (int)((rem + 15) / 16);
     dense_mask = (nsub >= 8) ? 0xffu : ((1u << nsub) - 1u);
   }
+  for (int e = tid; e < K * TM; e += 256) {
+    const int k = e / TM, r = e - k * TM;
+    int n;
+    if (p.nbr_s)
+      n = p.nbr_s[(int64_t)k * p.Vpad + row0 + r];
+    else
+      n = (row0 + r < p.V_out) ? (int)(row0 + r) : -1;
+    idx_s[e] = n;
+  }
 
-  for (int k = 0; k < p.K; ++k) {
-    const uint32_t sm = p.submask ? p.submask[(int64_t)tile * p.K + k] : dense_mask;
-    if (sm == 0) continue;
-    const uint32_t smw = (sm >> (wm * MR)) & ((1u << MR) - 1u);
-    const int32_t* nbr_k = p.nbr_s ? p.nbr_s + (int64_t)k * p.Vpad + row0 : nullptr;
-    const float* Wk = p.W + (int64_t)k * p.Cin * p.Cout;
+  // ---- step iterator over (active offset, chunk)
+  auto submask_of = [&](int k) -> uint32_t { return p.submask ? p.submask[(int64_t)tile * K + k] : dense_mask; };
+  int k_nxt = 0;
+  uint32_t sm_nxt = 0;
+  while (k_nxt < K && (sm_nxt = submask_of(k_nxt)) == 0) ++k_nxt;
+  int c_nxt = 0;
+  bool have_nxt = k_nxt < K;
 
-    // this thread's 4 gather rows (fixed over the channel chunks)
-    int arow[4];
+  float4 ra[4];
+  float4 rb[B_F4];
+  const int a_cc = (tid & 7) * 4;
+  const int a_r = tid >> 3;
+
+  auto issue_loads = [&](int k, int c0, uint32_t sm) {
+    // A: 128 gathered rows x 32 channels; thread -> rows a_r + 32j, channels c0 + a_cc .. +3
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      int r = (tid >> 3) + 32 * j;
-      int n = -1;
+      const int r = a_r + 32 * j;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if ((sm >> (r >> 4)) & 1u) {
-        if (nbr_k)
-          n = nbr_k[r];
-        else
-          n = (row0 + r < p.V_out) ? (int)(row0 + r) : -1;
+        const int n = idx_s[k * TM + r];
+        const int c = c0 + a_cc;
+        if (n >= 0) {
+          const float* src = p.in + (int64_t)n * p.in_ld + c;
+          if (p.vec_a) {
+            if (c < Cin) v = *(const float4*)src;
+          } else {
+            if (c + 0 < Cin) v.x = src[0];
+            if (c + 1 < Cin) v.y = src[1];
+            if (c + 2 < Cin) v.z = src[2];
+            if (c + 3 < Cin) v.w = src[3];
+          }
+        }
       }
-      arow[j] = n;
+      ra[j] = v;
     }
+    // B: 32 channels x TN output channels of W[k]
+    const float* Wk = p.W + (int64_t)k * Cin * Cout;
+    constexpr int F4_PER_ROW = TN / 4;
+#pragma unroll
+    for (int j = 0; j < B_F4; ++j) {
+      const int e = tid + 256 * j;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < KC * F4_PER_ROW) {
+        const int kk = e / F4_PER_ROW;
+        const int c4 = (e - kk * F4_PER_ROW) * 4;
+        const int c = c0 + kk;
+        const int col = n0 + c4;
+        if (c < Cin) {
+          const float* src = Wk + (int64_t)c * Cout + col;
+          if (p.vec_b) {
+            if (col < Cout) v = *(const float4*)src;
+          } else {
+            if (col + 0 < Cout) v.x = src[0];
+            if (col + 1 < Cout) v.y = src[1];
+            if (col + 2 < Cout) v.z = src[2];
+            if (col + 3 < Cout) v.w = src[3];
+          }
+        }
+      }
+      rb[j] = v;
+    }
+  };
 
-    for (int c0 = 0; c0 < p.Cin; c0 += KC) {
-      __syncthreads();  // previous chunk's MFMA reads are done
-      // ---- stage A: 128 rows x 32 channels, thread -> (row = tid/8 + 32j, 4 channels at (tid%8)*4)
-      {
-        const int cc = (tid & 7) * 4;
-        const int c = c0 + cc;
+  auto store_lds = [&](uint32_t sm) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int r = (tid >> 3) + 32 * j;
-          if (!((sm >> (r >> 4)) & 1u)) continue;  // sub-tile never read for this offset
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          const int n = arow[j];
-          if (n >= 0) {
-            const float* src = p.in + (int64_t)n * p.in_ld + c;
-            if (p.vec_a) {
-              if (c < p.Cin) v = *(const float4*)src;
-            } else {
-              if (c + 0 < p.Cin) v.x = src[0];
-              if (c + 1 < p.Cin) v.y = src[1];
-              if (c + 2 < p.Cin) v.z = src[2];
-              if (c + 3 < p.Cin) v.w = src[3];
-            }
-          }
-          float2* dst = (float2*)(As + r * SA + cc);
-          dst[0] = make_float2(v.x, v.y);
-          dst[1] = make_float2(v.z, v.w);
-        }
+    for (int j = 0; j < 4; ++j) {
+      const int r = a_r + 32 * j;
+      if ((sm >> (r >> 4)) & 1u) {
+        float2* dst = (float2*)(As + r * SA + a_cc);
+        dst[0] = make_float2(ra[j].x, ra[j].y);
+        dst[1] = make_float2(ra[j].z, ra[j].w);
       }
-      // ---- stage B: 32 channels x TN output channels
-      {
-        constexpr int F4_PER_ROW = TN / 4;
-        constexpr int TOTAL = KC * F4_PER_ROW;
+    }
+    constexpr int F4_PER_ROW = TN / 4;
 #pragma unroll
-        for (int e = tid; e < TOTAL; e += 256) {
-          const int kk = e / F4_PER_ROW;
-          const int c4 = (e - kk * F4_PER_ROW) * 4;
-          const int c = c0 + kk;
-          const int col = n0 + c4;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (c < p.Cin) {
-            const float* src = Wk + (int64_t)c * p.Cout + col;
-            if (p.vec_b) {
-              if (col < p.Cout) v = *(const float4*)src;
-            } else {
-              if (col + 0 < p.Cout) v.x = src[0];
-              if (col + 1 < p.Cout) v.y = src[1];
-              if (col + 2 < p.Cout) v.z = src[2];
-              if (col + 3 < p.Cout) v.w = src[3];
-            }
-          }
-          *(float4*)(Bs + kk * SB + c4) = v;
-        }
+    for (int j = 0; j < B_F4; ++j) {
+      const int e = tid + 256 * j;
+      if (e < KC * F4_PER_ROW) {
+        const int kk = e / F4_PER_ROW;
+        const int c4 = (e - kk * F4_PER_ROW) * 4;
+        *(float4*)(Bs + kk * SB + c4) = rb[j];
       }
-      __syncthreads();
-      // ---- MFMA over this chunk
-      const int kmax = min(KC, p.Cin - c0);
-      const int ksteps = (kmax + 3) >> 2;
-      const float* a_base = As + (wm * MR * 16 + li) * SA + lq;
-      const float* b_base = Bs + lq * SB + wn * NT * 16 + li;
-      for (int ks = 0; ks < ksteps; ++ks) {
-        float b[NT];
+    }
+  };
+
+  __syncthreads();  // idx_s visible
+  if (have_nxt) issue_loads(k_nxt, c_nxt, sm_nxt);
+
+  const float* a_base = As + (wm * MR * 16 + li) * SA + lq;
+  const float* b_base = Bs + lq * SB + wn * NT * 16 + li;
+
+  while (have_nxt) {
+    const int c_cur = c_nxt;
+    const uint32_t sm_cur = sm_nxt;
+    __syncthreads();  // every wave finished the previous step's LDS reads
+    store_lds(sm_cur);
+    __syncthreads();  // tiles visible
+    // advance the iterator and put the next step's loads in flight
+    c_nxt += KC;
+    if (c_nxt >= Cin) {
+      c_nxt = 0;
+      ++k_nxt;
+      while (k_nxt < K && (sm_nxt = submask_of(k_nxt)) == 0) ++k_nxt;
+      have_nxt = k_nxt < K;
+    }
+    if (have_nxt) issue_loads(k_nxt, c_nxt, sm_nxt);
+
+    // ---- MFMA over the current step; operand reads run one k-step ahead of the matrix ops
+    const uint32_t smw = (sm_cur >> (wm * MR)) & ((1u << MR) - 1u);
+    const int kmax = min(KC, Cin - c_cur);
+    const int ksteps = (kmax + 3) >> 2;
+    float a_cur[MR], b_cur[NT];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) b[n] = b_base[ks * 4 * SB + n * 16];
+    for (int s = 0; s < MR; ++s) a_cur[s] = a_base[s * 16 * SA];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) b_cur[n] = b_base[n * 16];
+#pragma unroll
+    for (int ks = 0; ks < KC / 4; ++ks) {
+      if (ks < ksteps) {
+        float a_nx[MR], b_nx[NT];
+        if (ks + 1 < KC / 4) {
+#pragma unroll
+          for (int s = 0; s < MR; ++s) a_nx[s] = a_base[s * 16 * SA + (ks + 1) * 4];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) b_nx[n] = b_base[(ks + 1) * 4 * SB + n * 16];
+        }
 #pragma unroll
         for (int s = 0; s < MR; ++s) {
           if ((smw >> s) & 1u) {
-            const float a = a_base[s * 16 * SA + ks * 4];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[s][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[n], acc[s][n], 0, 0, 0);
+            for (int n = 0; n < NT; ++n)
+              acc[s][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], b_cur[n], acc[s][n], 0, 0, 0);
           }
+        }
+        if (ks + 1 < KC / 4) {
+#pragma unroll
+          for (int s = 0; s < MR; ++s) a_cur[s] = a_nx[s];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) b_cur[n] = b_nx[n];
         }
       }
     }
@@ -188,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvParams p) {
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     const int col = n0 + wn * NT * 16 + n * 16 + li;
-    const bool col_ok = col < p.Cout;
+    const bool col_ok = col < Cout;
     const float sc = (p.scale && col_ok) ? p.scale[col] : 1.0f;
     const float sh = (p.shift && col_ok) ? p.shift[col] : 0.0f;
 #pragma unroll
@@ -221,8 +288,11 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvParams p) {
 template <int WAVES_N, int NT>
 static int launch_conv(const ConvParams& p, hipStream_t stream) {
   using Cfg = ConvCfg<WAVES_N, NT>;
-  dim3 grid((unsigned)(p.Vpad / TM), (unsigned)((p.Cout + Cfg::TN - 1) / Cfg::TN));
-  hipLaunchKernelGGL((conv_fwd_kernel<WAVES_N, NT>), grid, dim3(256), Cfg::LDS_BYTES, stream, p);
+  ConvParams q = p;
+  q.ntiles = (int)(p.Vpad / TM);
+  q.ny = (p.Cout + Cfg::TN - 1) / Cfg::TN;
+  dim3 grid((unsigned)(q.ntiles * q.ny));
+  hipLaunchKernelGGL((conv_fwd_kernel<WAVES_N, NT>), grid, dim3(256), Cfg::lds_bytes(p.K), stream, q);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }

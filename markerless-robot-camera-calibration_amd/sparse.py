@@ -73,10 +73,14 @@ class ConvPlan:
         self.V_out, self.Vpad, self.K = V_out, Vpad, K
         self.pairs = None  # number of (in,out) pairs, filled lazily for roofline accounting
 
-    def num_pairs(self):
+    def pairs_device(self):
+        """Number of (in, out) pairs of the kernel map as a device scalar (no host sync)."""
         if self.pairs is None:
-            self.pairs = int((self.nbr_s >= 0).sum().item())
+            self.pairs = (self.nbr_s >= 0).sum()
         return self.pairs
+
+    def num_pairs(self):
+        return int(self.pairs_device().item())
 
 
 class CoordinateManager:

@@ -1,0 +1,61 @@
+"""Single-layer microbenchmark of sv_conv_fwd on the Cfg-2 cloud (200k pts, 2 cm): k27 Cin->Cout at a chosen level.
+    python tools/conv_microbench.py [--cin 384 --cout 384 --level 0 --iters 10]
+Prints algorithmic TFLOP/s (2 P Cin Cout / time) and the plan's MFMA row-slot efficiency."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import mrcc_amd  # noqa: E402
+from mrcc_amd import MinkowskiEngine as ME  # noqa: E402
+from mrcc_amd import nn as svnn  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--cin", type=int, default=384)
+ap.add_argument("--cout", type=int, default=384)
+ap.add_argument("--level", type=int, default=0)
+ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--points", type=int, default=200000)
+ap.add_argument("--kind", default="k3")
+args = ap.parse_args()
+
+dev = torch.device("cuda:0")
+pts, rgb, _ = mrcc_amd.synth.gen_room(args.points, 2.4, 0)
+coords4 = np.concatenate([np.zeros((len(pts), 1), np.float32), pts * np.float32(50)], axis=1)
+x = ME.TensorField(torch.from_numpy(rgb), torch.from_numpy(coords4), device=dev).sparse()
+cm = x.coordinate_manager
+ts = 2 ** args.level
+if args.kind == "k3":
+    plan = cm.plan_k3(ts)
+    V_in = V = cm.stride_map(ts).V
+    K = 27
+elif args.kind == "dense":
+    plan = None
+    V_in = V = cm.stride_map(ts).V
+    K = 1
+torch.manual_seed(0)
+feats = torch.randn(V_in, args.cin, device=dev)
+W = torch.randn(K, args.cin, args.cout, device=dev) * 0.05
+P = plan.num_pairs() if plan is not None else V
+sub = plan.submask.cpu().numpy() if plan is not None else None
+if sub is not None:
+    slots = sum(bin(int(v)).count("1") for v in sub.reshape(-1)) * 16
+    print(f"V={V} pairs={P} row-slots={slots} slot-efficiency={P / slots:.3f} tiles={sub.shape[0]}")
+for _ in range(2):
+    out = svnn.conv_forward(feats, W, plan, V)
+torch.cuda.synchronize()
+s = torch.cuda.Event(enable_timing=True)
+e = torch.cuda.Event(enable_timing=True)
+s.record()
+for _ in range(args.iters):
+    out = svnn.conv_forward(feats, W, plan, V)
+e.record()
+torch.cuda.synchronize()
+ms = s.elapsed_time(e) / args.iters
+fl = 2.0 * P * args.cin * args.cout
+print(f"{args.kind} level{args.level} {args.cin}->{args.cout}: {ms:.3f} ms/launch, {fl / ms / 1e9:.1f} TFLOP/s algorithmic "
+      f"({fl / 1e9:.1f} GFLOP)")
