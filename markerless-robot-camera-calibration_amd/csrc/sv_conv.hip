@@ -45,30 +45,40 @@ struct ConvParams {
   int ny;
 };
 
-constexpr int TM = SV_TILE_ROWS;  // 128 rows per tile
-constexpr int KC = 32;            // input channels per LDS chunk
-constexpr int SA = KC + 2;        // A row stride in floats: conflict-free 16x16x4 operand reads
+constexpr int PLAN_TILE = SV_TILE_ROWS;  // plans (perm / nbr_s / submask) are laid out in 128-row tiles
+constexpr int KC = 32;                   // input channels per pipeline step
+constexpr int SA = KC + 2;               // A row stride in floats: conflict-free 16x16x4 operand reads
 
-template <int WAVES_N, int NT>
+// Workgroup = 4 waves.  Tile = TM_ output rows (mask-sorted plan order) x TN output channels.
+//   WAVES_N waves split the columns (NT 16-wide MFMA column tiles each), WAVES_M = 4 / WAVES_N split the rows.
+//   Column tiles are INTERLEAVED: MFMA column j of tile n is output channel n0 + wn*NT*16 + NT*j + n, so a lane's B
+//   operands for its NT tiles are NT consecutive floats of a weight row (one dwordxNT load straight from L2/HBM into
+//   registers — the weight slab is not shared between waves, an LDS round trip would be pure overhead) and the
+//   epilogue stores NT consecutive floats per lane.
+template <int TM_, int WAVES_N, int NT>
 struct ConvCfg {
   static constexpr int WAVES_M = 4 / WAVES_N;
-  static constexpr int MR = (TM / WAVES_M) / 16;  // 16-row sub-tiles per wave
-  static constexpr int TN = WAVES_N * NT * 16;    // output channels per workgroup
-  static constexpr int SB = TN + 16;              // B row stride in floats (== 16 mod 32)
-  static constexpr int B_F4 = (KC * TN / 4 + 255) / 256;  // float4 weight loads per thread and step
-  static constexpr size_t lds_bytes(int K) { return (size_t)(TM * SA + KC * SB + K * TM) * sizeof(float); }
+  static constexpr int MR = TM_ / WAVES_M / 16;  // 16-row sub-tiles per wave
+  static constexpr int TN = WAVES_N * NT * 16;   // output channels per workgroup
+  static constexpr int A_F4 = (TM_ * (KC / 4) + 255) / 256;  // float4 gathers per thread and step
+  static_assert(MR >= 1, "tile too small for the wave layout");
+  static constexpr size_t lds_bytes(int K) { return (size_t)(2 * TM_ * SA + K * TM_) * sizeof(float); }
 };
 
-// One pipeline step = (kernel offset k, input-channel chunk c0).  A step's global loads are issued into registers
-// BEFORE the previous step's MFMAs and written to LDS after them, so HBM/L2 latency hides under matrix work.
-template <int WAVES_N, int NT>
+// One pipeline step = (kernel offset k, input-channel chunk c0), visited in ascending (k, c0) order.
+//   A (gathered rows, TM_ x 32): global -> registers one step ahead -> LDS (double buffered), one barrier per step.
+//   B (weights, 32 x TN): global -> registers, re-loaded for the next step right after their last use.
+// FAST: float4 gathers, Cout a multiple of TN -> every load is unconditional (out-of-range lanes read a safe address and
+// are zeroed afterwards), so the loop body is straight-line and hipcc can emit COUNTED vmcnt waits; the generic
+// variant keeps per-lane guards (odd channel counts such as Cin = 3 or Cout = 3).
+template <int TM_, int WAVES_N, int NT, bool FAST>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
-  using Cfg = ConvCfg<WAVES_N, NT>;
-  constexpr int MR = Cfg::MR, TN = Cfg::TN, SB = Cfg::SB, B_F4 = Cfg::B_F4;
+  using Cfg = ConvCfg<TM_, WAVES_N, NT>;
+  constexpr int MR = Cfg::MR, TN = Cfg::TN, A_F4 = Cfg::A_F4;
+  constexpr int SUBS = TM_ / 16;  // sub-tiles per tile
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* As = lds;                              // [TM][SA]
-  float* Bs = lds + TM * SA;                    // [KC][SB]
-  int* idx_s = (int*)(lds + TM * SA + KC * SB);  // [K][TM] gathered input row of every (offset, tile row)
+  float* As = lds;                             // [2][TM_][SA]
+  int* idx_s = (int*)(lds + 2 * TM_ * SA);     // [K][TM_] gathered input row of every (offset, tile row)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -79,9 +89,11 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
   const int ny = p.ny;
   const int tile = p.ntiles - 1 - (int)(blockIdx.x / ny);
   const int n0 = (int)(blockIdx.x % ny) * TN;
-  const int64_t row0 = (int64_t)tile * TM;
+  const int64_t row0 = (int64_t)tile * TM_;
   const int li = lane & 15, lq = lane >> 4;
   const int K = p.K, Cin = p.Cin, Cout = p.Cout;
+  const int col0 = n0 + wn * NT * 16 + NT * li;  // this lane's first output channel
+  const bool cols_full = col0 + NT <= Cout;
 
   f32x4 acc[MR][NT];
 #pragma unroll
@@ -90,14 +102,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
     for (int n = 0; n < NT; ++n) acc[s][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // ---- stage the tile's neighbour table (or the identity for dense rows) in LDS
-  uint32_t dense_mask = 0xffu;
+  uint32_t dense_mask = (1u << SUBS) - 1u;
   if (p.submask == nullptr) {
     const int64_t rem = p.V_out - row0;
-    const int nsub = rem >= TM ? 8 : (int)((rem + 15) / 16);
-    dense_mask = (nsub >= 8) ? 0xffu : ((1u << nsub) - 1u);
+    const int nsub = rem >= TM_ ? SUBS : (int)((rem + 15) / 16);
+    dense_mask = (1u << nsub) - 1u;
   }
-  for (int e = tid; e < K * TM; e += 256) {
-    const int k = e / TM, r = e - k * TM;
+  for (int e = tid; e < K * TM_; e += 256) {
+    const int k = e / TM_, r = e - k * TM_;
     int n;
     if (p.nbr_s)
       n = p.nbr_s[(int64_t)k * p.Vpad + row0 + r];
@@ -106,195 +118,238 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
     idx_s[e] = n;
   }
 
-  // ---- step iterator over (active offset, chunk)
-  auto submask_of = [&](int k) -> uint32_t { return p.submask ? p.submask[(int64_t)tile * K + k] : dense_mask; };
-  int k_nxt = 0;
-  uint32_t sm_nxt = 0;
-  while (k_nxt < K && (sm_nxt = submask_of(k_nxt)) == 0) ++k_nxt;
-  int c_nxt = 0;
-  bool have_nxt = k_nxt < K;
-
-  float4 ra[4];
-  float4 rb[B_F4];
-  const int a_cc = (tid & 7) * 4;
-  const int a_r = tid >> 3;
-
-  auto issue_loads = [&](int k, int c0, uint32_t sm) {
-    // A: 128 gathered rows x 32 channels; thread -> rows a_r + 32j, channels c0 + a_cc .. +3
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = a_r + 32 * j;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((sm >> (r >> 4)) & 1u) {
-        const int n = idx_s[k * TM + r];
-        const int c = c0 + a_cc;
-        if (n >= 0) {
-          const float* src = p.in + (int64_t)n * p.in_ld + c;
-          if (p.vec_a) {
-            if (c < Cin) v = *(const float4*)src;
-          } else {
-            if (c + 0 < Cin) v.x = src[0];
-            if (c + 1 < Cin) v.y = src[1];
-            if (c + 2 < Cin) v.z = src[2];
-            if (c + 3 < Cin) v.w = src[3];
-          }
-        }
-      }
-      ra[j] = v;
-    }
-    // B: 32 channels x TN output channels of W[k]
-    const float* Wk = p.W + (int64_t)k * Cin * Cout;
-    constexpr int F4_PER_ROW = TN / 4;
-#pragma unroll
-    for (int j = 0; j < B_F4; ++j) {
-      const int e = tid + 256 * j;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e < KC * F4_PER_ROW) {
-        const int kk = e / F4_PER_ROW;
-        const int c4 = (e - kk * F4_PER_ROW) * 4;
-        const int c = c0 + kk;
-        const int col = n0 + c4;
-        if (c < Cin) {
-          const float* src = Wk + (int64_t)c * Cout + col;
-          if (p.vec_b) {
-            if (col < Cout) v = *(const float4*)src;
-          } else {
-            if (col + 0 < Cout) v.x = src[0];
-            if (col + 1 < Cout) v.y = src[1];
-            if (col + 2 < Cout) v.z = src[2];
-            if (col + 3 < Cout) v.w = src[3];
-          }
-        }
-      }
-      rb[j] = v;
+  // ---- step iterator over (active offset, chunk); the plan's submask words cover 128 rows = 8 sub-tiles
+  const int64_t sm_word = row0 / PLAN_TILE;
+  const int sm_shift = (int)((row0 % PLAN_TILE) / 16);
+  auto submask_of = [&](int k) -> uint32_t {
+    return p.submask ? ((p.submask[sm_word * K + k] >> sm_shift) & ((1u << SUBS) - 1u)) : dense_mask;
+  };
+  int k_n = 0;
+  uint32_t sm_n = 0;
+  while (k_n < K && (sm_n = submask_of(k_n)) == 0) ++k_n;
+  int c_n = 0;
+  bool have_n = k_n < K;
+  auto advance = [&]() {
+    c_n += KC;
+    if (c_n >= Cin) {
+      c_n = 0;
+      ++k_n;
+      while (k_n < K && (sm_n = submask_of(k_n)) == 0) ++k_n;
+      have_n = k_n < K;
     }
   };
 
-  auto store_lds = [&](uint32_t sm) {
+  float4 ra[A_F4];
+  const int a_cc = (tid & 7) * 4;
+  const int a_r = tid >> 3;
+
+  auto load_a = [&](int k, int c0, uint32_t sm) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < A_F4; ++j) {
       const int r = a_r + 32 * j;
-      if ((sm >> (r >> 4)) & 1u) {
-        float2* dst = (float2*)(As + r * SA + a_cc);
+      if (FAST) {
+        const int rr = (A_F4 * 32 > TM_) ? min(r, TM_ - 1) : r;
+        const int n = idx_s[k * TM_ + rr];
+        const int c = c0 + a_cc;
+        const bool ok = (r < TM_) && ((sm >> (rr >> 4)) & 1u) && (n >= 0) && (c < Cin);
+        const float* src = p.in + (ok ? ((int64_t)n * p.in_ld + c) : 0);
+        float4 v = *(const float4*)src;
+        ra[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < TM_ && ((sm >> (r >> 4)) & 1u)) {
+          const int n = idx_s[k * TM_ + r];
+          const int c = c0 + a_cc;
+          if (n >= 0) {
+            const float* src = p.in + (int64_t)n * p.in_ld + c;
+            if (p.vec_a) {
+              if (c < Cin) v = *(const float4*)src;
+            } else {
+              if (c + 0 < Cin) v.x = src[0];
+              if (c + 1 < Cin) v.y = src[1];
+              if (c + 2 < Cin) v.z = src[2];
+              if (c + 3 < Cin) v.w = src[3];
+            }
+          }
+        }
+        ra[j] = v;
+      }
+    }
+  };
+  auto store_a = [&](float* dstbuf, uint32_t sm) {
+#pragma unroll
+    for (int j = 0; j < A_F4; ++j) {
+      const int r = a_r + 32 * j;
+      if (r < TM_ && ((sm >> (r >> 4)) & 1u)) {
+        float2* dst = (float2*)(dstbuf + r * SA + a_cc);
         dst[0] = make_float2(ra[j].x, ra[j].y);
         dst[1] = make_float2(ra[j].z, ra[j].w);
       }
     }
-    constexpr int F4_PER_ROW = TN / 4;
+  };
+
+  // B operands of one k-step: rows c0 + 4 ks + lq of W[k], NT consecutive output channels starting at col0
+  float b[KC / 4][NT];
+  auto load_b = [&](int k, int c0, int ks, float (&dst)[NT]) {
+    const int c = c0 + 4 * ks + lq;
+    if (FAST) {
+      const bool ok = c < Cin;
+      const float* src = p.W + ((int64_t)k * Cin + (ok ? c : 0)) * Cout + col0;
 #pragma unroll
-    for (int j = 0; j < B_F4; ++j) {
-      const int e = tid + 256 * j;
-      if (e < KC * F4_PER_ROW) {
-        const int kk = e / F4_PER_ROW;
-        const int c4 = (e - kk * F4_PER_ROW) * 4;
-        *(float4*)(Bs + kk * SB + c4) = rb[j];
+      for (int n = 0; n < NT; ++n) {
+        const float v = src[n];
+        dst[n] = ok ? v : 0.0f;
       }
+    } else {
+      const float* src = p.W + ((int64_t)k * Cin + c) * Cout + col0;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) dst[n] = (c < Cin && col0 + n < Cout) ? src[n] : 0.0f;
     }
   };
 
   __syncthreads();  // idx_s visible
-  if (have_nxt) issue_loads(k_nxt, c_nxt, sm_nxt);
+  if (have_n) {
+    // ---- prologue: step 0 operands, step 1 gathers in flight
+    int k_c = k_n, c_c = c_n;
+    uint32_t sm_c = sm_n;
+    load_a(k_c, c_c, sm_c);
+#pragma unroll
+    for (int ks = 0; ks < KC / 4; ++ks) load_b(k_c, c_c, ks, b[ks]);
+    store_a(As, sm_c);
+    advance();
+    if (FAST || have_n) load_a(have_n ? k_n : 0, c_n, sm_n);
+    __syncthreads();
+    int buf = 0;
 
-  const float* a_base = As + (wm * MR * 16 + li) * SA + lq;
-  const float* b_base = Bs + lq * SB + wn * NT * 16 + li;
-
-  while (have_nxt) {
-    const int c_cur = c_nxt;
-    const uint32_t sm_cur = sm_nxt;
-    __syncthreads();  // every wave finished the previous step's LDS reads
-    store_lds(sm_cur);
-    __syncthreads();  // tiles visible
-    // advance the iterator and put the next step's loads in flight
-    c_nxt += KC;
-    if (c_nxt >= Cin) {
-      c_nxt = 0;
-      ++k_nxt;
-      while (k_nxt < K && (sm_nxt = submask_of(k_nxt)) == 0) ++k_nxt;
-      have_nxt = k_nxt < K;
-    }
-    if (have_nxt) issue_loads(k_nxt, c_nxt, sm_nxt);
-
-    // ---- MFMA over the current step; operand reads run one k-step ahead of the matrix ops
-    const uint32_t smw = (sm_cur >> (wm * MR)) & ((1u << MR) - 1u);
-    const int kmax = min(KC, Cin - c_cur);
-    const int ksteps = (kmax + 3) >> 2;
-    float a_cur[MR], b_cur[NT];
+    for (;;) {
+      // ---- MFMA over the current step; A operand reads run one k-step ahead of the matrix ops; each k-step's B
+      //      registers are refilled for the NEXT step as soon as the matrix ops that read them are issued
+      const float* a_base = As + buf * (TM_ * SA) + (wm * MR * 16 + li) * SA + lq;
+      const uint32_t smw = (sm_c >> (wm * MR)) & ((1u << MR) - 1u);
+      const int kmax = min(KC, Cin - c_c);
+      const int ksteps = (kmax + 3) >> 2;
+      float a_cur[MR];
 #pragma unroll
-    for (int s = 0; s < MR; ++s) a_cur[s] = a_base[s * 16 * SA];
+      for (int s = 0; s < MR; ++s) a_cur[s] = a_base[s * 16 * SA];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) b_cur[n] = b_base[n * 16];
+      for (int ks = 0; ks < KC / 4; ++ks) {
+        if (ks < ksteps) {
+          float a_nx[MR];
+          if (ks + 1 < KC / 4) {
 #pragma unroll
-    for (int ks = 0; ks < KC / 4; ++ks) {
-      if (ks < ksteps) {
-        float a_nx[MR], b_nx[NT];
-        if (ks + 1 < KC / 4) {
+            for (int s = 0; s < MR; ++s) a_nx[s] = a_base[s * 16 * SA + (ks + 1) * 4];
+          }
 #pragma unroll
-          for (int s = 0; s < MR; ++s) a_nx[s] = a_base[s * 16 * SA + (ks + 1) * 4];
+          for (int s = 0; s < MR; ++s) {
+            if ((smw >> s) & 1u) {
 #pragma unroll
-          for (int n = 0; n < NT; ++n) b_nx[n] = b_base[(ks + 1) * 4 * SB + n * 16];
-        }
+              for (int n = 0; n < NT; ++n)
+                acc[s][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], b[ks][n], acc[s][n], 0, 0, 0);
+            }
+          }
+          if (ks + 1 < KC / 4) {
 #pragma unroll
-        for (int s = 0; s < MR; ++s) {
-          if ((smw >> s) & 1u) {
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-              acc[s][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], b_cur[n], acc[s][n], 0, 0, 0);
+            for (int s = 0; s < MR; ++s) a_cur[s] = a_nx[s];
           }
         }
-        if (ks + 1 < KC / 4) {
-#pragma unroll
-          for (int s = 0; s < MR; ++s) a_cur[s] = a_nx[s];
-#pragma unroll
-          for (int n = 0; n < NT; ++n) b_cur[n] = b_nx[n];
-        }
+        if (FAST || have_n) load_b(have_n ? k_n : 0, c_n, ks, b[ks]);
       }
+      if (!have_n) break;
+      // ---- hand over to the next step
+      store_a(As + (buf ^ 1) * (TM_ * SA), sm_n);
+      k_c = k_n;
+      c_c = c_n;
+      sm_c = sm_n;
+      advance();
+      if (FAST || have_n) load_a(have_n ? k_n : 0, c_n, sm_n);
+      __syncthreads();
+      buf ^= 1;
     }
   }
 
-  // ---- epilogue: BN(eval)/bias -> residual -> activation -> store (C/D map: col = lane&15, row = (lane>>4)*4 + reg)
+  // ---- epilogue: BN(eval)/bias -> residual -> activation -> store.  C/D map: MFMA col = lane&15, row = (lane>>4)*4+reg
+  float sc[NT], sh[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    const int col = n0 + wn * NT * 16 + n * 16 + li;
-    const bool col_ok = col < Cout;
-    const float sc = (p.scale && col_ok) ? p.scale[col] : 1.0f;
-    const float sh = (p.shift && col_ok) ? p.shift[col] : 0.0f;
+    const bool ok = col0 + n < Cout;
+    sc[n] = (p.scale && ok) ? p.scale[col0 + n] : 1.0f;
+    sh[n] = (p.shift && ok) ? p.shift[col0 + n] : 0.0f;
+  }
 #pragma unroll
-    for (int s = 0; s < MR; ++s) {
+  for (int s = 0; s < MR; ++s) {
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int64_t r = row0 + wm * MR * 16 + s * 16 + lq * 4 + reg;
-        int64_t o;
-        if (p.perm)
-          o = p.perm[r];
-        else
-          o = (r < p.V_out) ? r : -1;
-        if (o < 0 || !col_ok) continue;
-        float y = acc[s][n][reg];
+    for (int reg = 0; reg < 4; ++reg) {
+      const int64_t r = row0 + wm * MR * 16 + s * 16 + lq * 4 + reg;
+      int64_t o;
+      if (p.perm)
+        o = p.perm[r];
+      else
+        o = (r < p.V_out) ? r : -1;
+      if (o < 0) continue;
+      float y[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        float v = acc[s][n][reg];
         if (p.scale)
-          y = __builtin_fmaf(y, sc, sh);
+          v = __builtin_fmaf(v, sc[n], sh[n]);
         else if (p.shift)
-          y = y + sh;
-        if (p.residual) y = y + p.residual[o * p.res_ld + col];
+          v = v + sh[n];
+        y[n] = v;
+      }
+      if (p.residual) {
+        const float* res = p.residual + o * p.res_ld + col0;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          if (col0 + n < Cout) y[n] = y[n] + res[n];
+      }
+      float* dst = p.out + o * p.out_ld + col0;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        float v = y[n];
         if (p.act == SV_ACT_RELU)
-          y = y > 0.f ? y : 0.f;
+          v = v > 0.f ? v : 0.f;
         else if (p.act == SV_ACT_LEAKY_RELU)
-          y = y > 0.f ? y : y * p.slope;
-        p.out[o * p.out_ld + col] = y;
+          v = v > 0.f ? v : v * p.slope;
+        if (col0 + n < Cout) dst[n] = v;
       }
     }
   }
 }
 
-template <int WAVES_N, int NT>
+template <int TM_, int WAVES_N, int NT>
 static int launch_conv(const ConvParams& p, hipStream_t stream) {
-  using Cfg = ConvCfg<WAVES_N, NT>;
+  using Cfg = ConvCfg<TM_, WAVES_N, NT>;
   ConvParams q = p;
-  q.ntiles = (int)(p.Vpad / TM);
+  q.ntiles = (int)(p.Vpad / TM_);
   q.ny = (p.Cout + Cfg::TN - 1) / Cfg::TN;
   dim3 grid((unsigned)(q.ntiles * q.ny));
-  hipLaunchKernelGGL((conv_fwd_kernel<WAVES_N, NT>), grid, dim3(256), Cfg::lds_bytes(p.K), stream, q);
+  const bool fast = p.vec_a && (p.Cout % Cfg::TN == 0);
+  if (fast)
+    hipLaunchKernelGGL((conv_fwd_kernel<TM_, WAVES_N, NT, true>), grid, dim3(256), Cfg::lds_bytes(p.K), stream, q);
+  else
+    hipLaunchKernelGGL((conv_fwd_kernel<TM_, WAVES_N, NT, false>), grid, dim3(256), Cfg::lds_bytes(p.K), stream, q);
   SV_LAUNCH_CHECK();
   return SV_OK;
+}
+
+// tile height: the tallest tile that still gives the chip enough workgroups (a tile is processed sequentially:
+// K * Cin/32 steps, so few tall tiles = a latency-bound launch)
+template <int WAVES_N, int NT>
+static int launch_conv_rows(const ConvParams& p, hipStream_t stream) {
+  constexpr int TN = WAVES_N * NT * 16;
+  constexpr int MIN_TM = 16 * (4 / WAVES_N);
+  const int64_t ny = (p.Cout + TN - 1) / TN;
+  const int64_t want = 768;  // ~3 workgroups per CU
+  auto wgs = [&](int tm) { return (p.Vpad / tm) * ny; };
+  if (wgs(128) >= want || MIN_TM > 64) return launch_conv<128, WAVES_N, NT>(p, stream);
+  if constexpr (MIN_TM <= 64) {
+    if (wgs(64) >= want || MIN_TM > 32) return launch_conv<64, WAVES_N, NT>(p, stream);
+  }
+  if constexpr (MIN_TM <= 32) {
+    if (wgs(32) >= want || MIN_TM > 16) return launch_conv<32, WAVES_N, NT>(p, stream);
+  }
+  if constexpr (MIN_TM <= 16) return launch_conv<16, WAVES_N, NT>(p, stream);
+  return SV_ERR_INVALID;
 }
 
 }  // namespace sv
@@ -307,7 +362,7 @@ extern "C" int sv_conv_fwd(const float* in, int64_t in_ld, int Cin, const float*
                            int act, float slope, float* out, int64_t out_ld, sv_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SV_CHECK_ARG(Cin > 0 && Cout > 0 && K >= 1 && K <= 32, "bad channel / kernel volume");
-  SV_CHECK_ARG(V_out >= 0 && Vpad >= V_out && Vpad % TM == 0, "Vpad must be a multiple of 128 >= V_out");
+  SV_CHECK_ARG(V_out >= 0 && Vpad >= V_out && Vpad % PLAN_TILE == 0, "Vpad must be a multiple of 128 >= V_out");
   SV_CHECK_ARG(in_ld >= Cin && out_ld >= Cout, "row strides too small");
   SV_CHECK_ARG(act >= SV_ACT_NONE && act <= SV_ACT_LEAKY_RELU, "bad activation");
   if (V_out == 0) return SV_OK;
@@ -323,13 +378,15 @@ extern "C" int sv_conv_fwd(const float* in, int64_t in_ld, int Cin, const float*
   p.act = act; p.slope = slope; p.out = out; p.out_ld = out_ld;
   p.vec_a = (in_ld % 4 == 0) && (Cin % 4 == 0) && (((uintptr_t)in & 15) == 0);
   p.vec_b = (Cout % 4 == 0) && (((uintptr_t)W & 15) == 0);
+  p.ntiles = 0;
+  p.ny = 0;
   if (Cout > 128) {
     // 192-wide tiles waste least for 384; 128-wide for 256 / 1024 / 2048
-    if (Cout % 192 == 0 || Cout > 2048) return launch_conv<4, 3>(p, stream);
-    return launch_conv<4, 2>(p, stream);
+    if (Cout % 192 == 0 || Cout > 2048) return launch_conv_rows<4, 3>(p, stream);
+    return launch_conv_rows<4, 2>(p, stream);
   }
-  if (Cout > 64) return launch_conv<4, 2>(p, stream);
-  if (Cout > 32) return launch_conv<4, 1>(p, stream);
-  if (Cout > 16) return launch_conv<2, 1>(p, stream);
-  return launch_conv<1, 1>(p, stream);
+  if (Cout > 64) return launch_conv_rows<4, 2>(p, stream);
+  if (Cout > 32) return launch_conv_rows<4, 1>(p, stream);
+  if (Cout > 16) return launch_conv_rows<2, 1>(p, stream);
+  return launch_conv_rows<1, 1>(p, stream);
 }

@@ -47,7 +47,7 @@ def conv_forward(feats, weight3, plan, V_out, scale=None, shift=None, residual=N
          c_int64(residual.stride(0) if residual is not None else 0), c_int(act), c_float(slope), ptr(out),
          c_int64(out.stride(0)), stream_ptr())
     if t0 is not None:
-        timer.stop(t0, profiling.conv_kernel_config(Cout), K, Cin, Cout, V_out,
+        timer.stop(t0, profiling.conv_kernel_config(Cout, Vpad), K, Cin, Cout, V_out,
                    plan.pairs_device() if plan is not None else None)
     return out
 

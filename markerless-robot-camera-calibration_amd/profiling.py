@@ -9,17 +9,30 @@ import torch
 TIMER = None  # set by bench.py
 
 
-def conv_kernel_config(Cout):
-    """Mirror of the dispatch in csrc/sv_conv.hip:sv_conv_fwd -> template instance name as rocprofv3 prints it."""
+def conv_kernel_config(Cout, Vpad):
+    """Mirror of the dispatch in csrc/sv_conv.hip (sv_conv_fwd + launch_conv_rows) -> template instance name as
+    rocprofv3 prints it: conv_fwd_kernel<TM, WAVES_N, NT>."""
     if Cout > 128:
-        return "conv_fwd_kernel<4, 3>" if (Cout % 192 == 0 or Cout > 2048) else "conv_fwd_kernel<4, 2>"
-    if Cout > 64:
-        return "conv_fwd_kernel<4, 2>"
-    if Cout > 32:
-        return "conv_fwd_kernel<4, 1>"
-    if Cout > 16:
-        return "conv_fwd_kernel<2, 1>"
-    return "conv_fwd_kernel<1, 1>"
+        wn, nt = (4, 3) if (Cout % 192 == 0 or Cout > 2048) else (4, 2)
+    elif Cout > 64:
+        wn, nt = 4, 2
+    elif Cout > 32:
+        wn, nt = 4, 1
+    elif Cout > 16:
+        wn, nt = 2, 1
+    else:
+        wn, nt = 1, 1
+    tn = wn * nt * 16
+    min_tm = 16 * (4 // wn)
+    ny = (Cout + tn - 1) // tn
+    tm = min_tm
+    for cand in (128, 64, 32, 16):
+        if cand < min_tm:
+            break
+        tm = cand
+        if (Vpad // cand) * ny >= 768:
+            break
+    return f"conv_fwd_kernel<{tm}, {wn}, {nt}>"
 
 
 class KernelTimer:
