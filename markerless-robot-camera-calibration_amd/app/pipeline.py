@@ -1,0 +1,79 @@
+"""Two-stream frame pipeline: coordinate work of frame i+1 overlaps the U-Net of frame i.
+
+Per frame the host must read a handful of sizes back from the GPU (voxel count of every pyramid level) before it can
+allocate and launch the next stage.  On a single stream each read-back waits for everything queued before it —
+including the previous frame's ~30 ms of convolutions — so host and GPU take turns.  Here the voxelisation, coordinate
+maps, kernel maps and conv plans of a frame are built on a PREP stream (its read-backs only wait for its own small
+kernels) while the previous frame's convolutions run on the COMPUTE stream; an event hands the prepared frame over.
+Prepared frames are kept alive until the compute stream has finished with them, so the caching allocator cannot
+recycle their memory under a running kernel.
+"""
+import collections
+
+import torch
+
+from .. import MinkowskiEngine as ME
+
+
+class PreparedFrame:
+    __slots__ = ("field", "x", "ready", "done", "tag")
+
+    def __init__(self, field, x, ready, tag=None):
+        self.field, self.x, self.ready, self.done, self.tag = field, x, ready, None, tag
+
+
+def build_unet_plans(cm, levels=4):
+    """Everything a MinkUNet-shaped graph will ask the coordinate manager for (model/backbone/minkunet.py:125-183):
+    3x3x3 maps at strides 1..2^levels, stride-2 down maps and transposed up maps between neighbouring levels."""
+    for l in range(levels):
+        ts = 1 << l
+        cm.plan_k3(ts)
+        cm.plan_down(ts)
+    cm.plan_k3(1 << levels)
+    for l in range(levels, 0, -1):
+        cm.plan_up(1 << l)
+
+
+class FramePipeline:
+    def __init__(self, device, levels=4, encoder_only=False):
+        self.device = torch.device(device)
+        self.levels = levels
+        self.encoder_only = encoder_only
+        self.prep_stream = torch.cuda.Stream(device=self.device)
+        self._retired = collections.deque()
+
+    def prepare(self, coords4, feats, tag=None):
+        """Enqueue voxelisation + coordinate/kernel maps + plans of one frame on the prep stream.
+        coords4: float32 [N,4] (batch, x*scale, y*scale, z*scale) on the GPU; feats: float32 [N,C] on the GPU."""
+        with torch.cuda.stream(self.prep_stream):
+            field = ME.TensorField(features=feats, coordinates=coords4,
+                                   quantization_mode=ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE,
+                                   minkowski_algorithm=ME.MinkowskiAlgorithm.SPEED_OPTIMIZED, device=self.device)
+            x = field.sparse()
+            cm = x.coordinate_manager
+            if self.encoder_only:
+                for l in range(self.levels):
+                    cm.plan_k3(1 << l)
+                    cm.plan_down(1 << l)
+                cm.plan_k3(1 << self.levels)
+            else:
+                build_unet_plans(cm, self.levels)
+            ready = torch.cuda.Event()
+            ready.record(self.prep_stream)
+        return PreparedFrame(field, x, ready, tag)
+
+    def run(self, prepared, fn):
+        """Run fn(x, field) on the current (compute) stream once the frame is ready; returns fn's result."""
+        compute = torch.cuda.current_stream(self.device)
+        compute.wait_event(prepared.ready)
+        out = fn(prepared.x, prepared.field)
+        prepared.done = torch.cuda.Event()
+        prepared.done.record(compute)
+        self._retired.append(prepared)
+        while self._retired and self._retired[0].done.query():
+            self._retired.popleft()
+        return out
+
+    def drain(self):
+        torch.cuda.current_stream(self.device).synchronize()
+        self._retired.clear()

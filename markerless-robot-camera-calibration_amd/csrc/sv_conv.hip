@@ -46,8 +46,9 @@ struct ConvParams {
 };
 
 constexpr int PLAN_TILE = SV_TILE_ROWS;  // plans (perm / nbr_s / submask) are laid out in 128-row tiles
-constexpr int KC = 32;                   // input channels per pipeline step
-constexpr int SA = KC + 2;               // A row stride in floats: conflict-free 16x16x4 operand reads
+// input channels per pipeline step: short tiles (used on small pyramid levels, where a launch is bound by the latency
+// of a tile's sequential step chain) take wider chunks, i.e. fewer barriers / gather round trips per tile
+constexpr int chunk_for(int tm) { return tm <= 16 ? 128 : (tm <= 32 ? 64 : 32); }
 
 // Workgroup = 4 waves.  Tile = TM_ output rows (mask-sorted plan order) x TN output channels.
 //   WAVES_N waves split the columns (NT 16-wide MFMA column tiles each), WAVES_M = 4 / WAVES_N split the rows.
@@ -60,7 +61,11 @@ struct ConvCfg {
   static constexpr int WAVES_M = 4 / WAVES_N;
   static constexpr int MR = TM_ / WAVES_M / 16;  // 16-row sub-tiles per wave
   static constexpr int TN = WAVES_N * NT * 16;   // output channels per workgroup
-  static constexpr int A_F4 = (TM_ * (KC / 4) + 255) / 256;  // float4 gathers per thread and step
+  static constexpr int KC = chunk_for(TM_);
+  static constexpr int SA = KC + 2;              // A row stride in floats: conflict-free 16x16x4 operand reads
+  static constexpr int F4_PER_ROW = KC / 4;      // float4 per gathered row and step
+  static constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
+  static constexpr int A_F4 = (TM_ + ROWS_PER_PASS - 1) / ROWS_PER_PASS;  // float4 gathers per thread and step
   static_assert(MR >= 1, "tile too small for the wave layout");
   static constexpr size_t lds_bytes(int K) { return (size_t)(2 * TM_ * SA + K * TM_) * sizeof(float); }
 };
@@ -74,7 +79,8 @@ struct ConvCfg {
 template <int TM_, int WAVES_N, int NT, bool FAST>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
   using Cfg = ConvCfg<TM_, WAVES_N, NT>;
-  constexpr int MR = Cfg::MR, TN = Cfg::TN, A_F4 = Cfg::A_F4;
+  constexpr int MR = Cfg::MR, TN = Cfg::TN, A_F4 = Cfg::A_F4, KC = Cfg::KC, SA = Cfg::SA;
+  constexpr int ROWS_PER_PASS = Cfg::ROWS_PER_PASS;
   constexpr int SUBS = TM_ / 16;  // sub-tiles per tile
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* As = lds;                             // [2][TM_][SA]
@@ -140,15 +146,15 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
   };
 
   float4 ra[A_F4];
-  const int a_cc = (tid & 7) * 4;
-  const int a_r = tid >> 3;
+  const int a_cc = (tid % Cfg::F4_PER_ROW) * 4;
+  const int a_r = tid / Cfg::F4_PER_ROW;
 
   auto load_a = [&](int k, int c0, uint32_t sm) {
 #pragma unroll
     for (int j = 0; j < A_F4; ++j) {
-      const int r = a_r + 32 * j;
+      const int r = a_r + ROWS_PER_PASS * j;
       if (FAST) {
-        const int rr = (A_F4 * 32 > TM_) ? min(r, TM_ - 1) : r;
+        const int rr = (A_F4 * ROWS_PER_PASS > TM_) ? min(r, TM_ - 1) : r;
         const int n = idx_s[k * TM_ + rr];
         const int c = c0 + a_cc;
         const bool ok = (r < TM_) && ((sm >> (rr >> 4)) & 1u) && (n >= 0) && (c < Cin);
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
   auto store_a = [&](float* dstbuf, uint32_t sm) {
 #pragma unroll
     for (int j = 0; j < A_F4; ++j) {
-      const int r = a_r + 32 * j;
+      const int r = a_r + ROWS_PER_PASS * j;
       if (r < TM_ && ((sm >> (r >> 4)) & 1u)) {
         float2* dst = (float2*)(dstbuf + r * SA + a_cc);
         dst[0] = make_float2(ra[j].x, ra[j].y);
@@ -190,22 +196,23 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
 
   // B operands of one k-step: rows c0 + 4 ks + lq of W[k], NT consecutive output channels starting at col0
   float b[KC / 4][NT];
-  auto load_b = [&](int k, int c0, int ks, float (&dst)[NT]) {
-    const int c = c0 + 4 * ks + lq;
+  // FAST: wstep = first weight row of the step (wave-uniform -> scalar registers), b_off = this lane's constant offset;
+  // per k-step only a scalar add remains.  K-steps past the channel tail re-read row 0 of the step (never multiplied).
+  const int b_off = lq * Cout + col0;
+  auto step_weights = [&](int k, int c0) -> const float* { return p.W + ((int64_t)k * Cin + c0) * Cout; };
+  auto load_b = [&](const float* wstep, int k, int c0, int ksteps_valid, int ks, float (&dst)[NT]) {
     if (FAST) {
-      const bool ok = c < Cin;
-      const float* src = p.W + ((int64_t)k * Cin + (ok ? c : 0)) * Cout + col0;
+      const float* src = wstep + (int64_t)(ks < ksteps_valid ? 4 * ks : 0) * Cout;
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const float v = src[n];
-        dst[n] = ok ? v : 0.0f;
-      }
+      for (int n = 0; n < NT; ++n) dst[n] = src[b_off + n];
     } else {
+      const int c = c0 + 4 * ks + lq;
       const float* src = p.W + ((int64_t)k * Cin + c) * Cout + col0;
 #pragma unroll
       for (int n = 0; n < NT; ++n) dst[n] = (c < Cin && col0 + n < Cout) ? src[n] : 0.0f;
     }
   };
+  auto ksteps_of = [&](int c0) { return (min(KC, Cin - c0) + 3) >> 2; };
 
   __syncthreads();  // idx_s visible
   if (have_n) {
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
     uint32_t sm_c = sm_n;
     load_a(k_c, c_c, sm_c);
 #pragma unroll
-    for (int ks = 0; ks < KC / 4; ++ks) load_b(k_c, c_c, ks, b[ks]);
+    for (int ks = 0; ks < KC / 4; ++ks) load_b(step_weights(k_c, c_c), k_c, c_c, ksteps_of(c_c), ks, b[ks]);
     store_a(As, sm_c);
     advance();
     if (FAST || have_n) load_a(have_n ? k_n : 0, c_n, sm_n);
@@ -226,8 +233,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
       //      registers are refilled for the NEXT step as soon as the matrix ops that read them are issued
       const float* a_base = As + buf * (TM_ * SA) + (wm * MR * 16 + li) * SA + lq;
       const uint32_t smw = (sm_c >> (wm * MR)) & ((1u << MR) - 1u);
-      const int kmax = min(KC, Cin - c_c);
-      const int ksteps = (kmax + 3) >> 2;
+      const int ksteps = ksteps_of(c_c);
+      const int kb = have_n ? k_n : 0;
+      const float* wnext = step_weights(kb, c_n);
+      const int ksteps_next = ksteps_of(c_n);
       float a_cur[MR];
 #pragma unroll
       for (int s = 0; s < MR; ++s) a_cur[s] = a_base[s * 16 * SA];
@@ -241,7 +250,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
           }
 #pragma unroll
           for (int s = 0; s < MR; ++s) {
-            if ((smw >> s) & 1u) {
+            // a tile with ONE sub-tile per wave row group is only visited for offsets where that sub-tile is active
+            // (steps with an empty submask are skipped), so the test is compile-time true there
+            if ((MR == 1 && Cfg::WAVES_M == 1) || ((smw >> s) & 1u)) {
 #pragma unroll
               for (int n = 0; n < NT; ++n)
                 acc[s][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], b[ks][n], acc[s][n], 0, 0, 0);
@@ -252,7 +263,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
             for (int s = 0; s < MR; ++s) a_cur[s] = a_nx[s];
           }
         }
-        if (FAST || have_n) load_b(have_n ? k_n : 0, c_n, ks, b[ks]);
+        if (FAST || have_n) load_b(wnext, kb, c_n, ksteps_next, ks, b[ks]);
       }
       if (!have_n) break;
       // ---- hand over to the next step
@@ -341,7 +352,10 @@ static int launch_conv_rows(const ConvParams& p, hipStream_t stream) {
   const int64_t ny = (p.Cout + TN - 1) / TN;
   const int64_t want = 768;  // ~3 workgroups per CU
   auto wgs = [&](int tm) { return (p.Vpad / tm) * ny; };
-  if (wgs(128) >= want || MIN_TM > 64) return launch_conv<128, WAVES_N, NT>(p, stream);
+  constexpr bool ALLOW_128 = !(WAVES_N == 4 && NT == 1);  // that instance runs out of registers
+  if constexpr (ALLOW_128) {
+    if (wgs(128) >= want || MIN_TM > 64) return launch_conv<128, WAVES_N, NT>(p, stream);
+  }
   if constexpr (MIN_TM <= 64) {
     if (wgs(64) >= want || MIN_TM > 32) return launch_conv<64, WAVES_N, NT>(p, stream);
   }

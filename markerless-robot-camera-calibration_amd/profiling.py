@@ -27,6 +27,8 @@ def conv_kernel_config(Cout, Vpad):
     ny = (Cout + tn - 1) // tn
     tm = min_tm
     for cand in (128, 64, 32, 16):
+        if cand == 128 and (wn, nt) == (4, 1):
+            continue
         if cand < min_tm:
             break
         tm = cand
