@@ -56,6 +56,7 @@ def run_frames(model, pipe, frames, steps, hist=None):
     is voxelised and mapped from scratch; all work of all `steps` frames is enqueued (and, by the caller's
     synchronize, finished) inside the caller's timed region."""
     voxels = 0
+    cls = torch.arange(3, device=frames[0][1].device).unsqueeze(1)
 
     def unet(x, field):
         out = model(x)
@@ -66,8 +67,8 @@ def run_frames(model, pipe, frames, steps, hist=None):
     for i in range(steps):
         cur = nxt
         label = pipe.run(cur, unet)
-        if hist is not None:
-            hist += torch.bincount(label, minlength=3)
+        if hist is not None:  # asynchronous label histogram (torch.bincount would synchronise host and GPU every frame)
+            hist += (label.unsqueeze(0) == cls).sum(dim=1)
         voxels += cur.x.F.shape[0]
         if i + 1 < steps:
             nxt = pipe.prepare(*frames[(i + 1) % len(frames)][:2])
