@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pool", type=int, default=4, help="distinct frames resident per rank")
+    ap.add_argument("--no-kernel-timer", action="store_true", help="diagnostic: drop the per-launch HIP events")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -140,8 +141,8 @@ def main():
         if args.warmup:
             run_frames(model, pipe, frames, args.warmup)
             pipe.drain()
-        timer = profiling.KernelTimer()
-        profiling.TIMER = timer
+        timer = profiling.KernelTimer(capacity=2 * 64 * args.steps + 64)
+        profiling.TIMER = None if args.no_kernel_timer else timer
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()

@@ -13,6 +13,8 @@
 // Numerics: every output element is ONE f32 fma chain over (k ascending, c ascending) — the MFMA is a k-ordered
 // fmaf chain (MI355X guide §3) — so results are bitwise reproducible and match oracle/sv_oracle.c exactly.
 // A missing neighbour contributes fma(0, w, acc) = acc.
+#include <stdlib.h>
+
 #include "sv_common.h"
 
 namespace sv {
@@ -350,7 +352,8 @@ static int launch_conv_rows(const ConvParams& p, hipStream_t stream) {
   constexpr int TN = WAVES_N * NT * 16;
   constexpr int MIN_TM = 16 * (4 / WAVES_N);
   const int64_t ny = (p.Cout + TN - 1) / TN;
-  const int64_t want = 768;  // ~3 workgroups per CU
+  int64_t want = 1500;  // ~6 workgroups per CU: short tail, measured optimum on the Cfg-2 pyramid
+  if (const char* e = getenv("SV_CONV_MIN_WGS")) want = atoll(e);  // tuning knob (experiments only)
   auto wgs = [&](int tm) { return (p.Vpad / tm) * ny; };
   constexpr bool ALLOW_128 = !(WAVES_N == 4 && NT == 1);  // that instance runs out of registers
   if constexpr (ALLOW_128) {

@@ -32,23 +32,33 @@ def conv_kernel_config(Cout, Vpad):
         if cand < min_tm:
             break
         tm = cand
-        if (Vpad // cand) * ny >= 768:
+        if (Vpad // cand) * ny >= 1500:
             break
     return f"conv_fwd_kernel<{tm}, {wn}, {nt}>"
 
 
 class KernelTimer:
-    def __init__(self):
+    def __init__(self, capacity=0):
         self.records = []
         self.enabled = True
+        # events are created up front: creating ~250 of them per frame inside the timed region costs milliseconds
+        self._pool = [torch.cuda.Event(enable_timing=True) for _ in range(capacity)]
+        self._next = 0
+
+    def _event(self):
+        if self._next < len(self._pool):
+            e = self._pool[self._next]
+            self._next += 1
+            return e
+        return torch.cuda.Event(enable_timing=True)
 
     def start(self):
-        e = torch.cuda.Event(enable_timing=True)
+        e = self._event()
         e.record()
         return e
 
     def stop(self, start_evt, kernel, K, Cin, Cout, V_out, pairs_dev):
-        e = torch.cuda.Event(enable_timing=True)
+        e = self._event()
         e.record()
         self.records.append((kernel, K, Cin, Cout, V_out, pairs_dev, start_evt, e))
 
