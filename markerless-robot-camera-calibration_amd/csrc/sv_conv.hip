@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
 
   __syncthreads();  // idx_s visible
   if (have_n) {
-    // ---- prologue: step 0 operands, step 1 gathers in flight
+    // ---- prologue: step 0 operands
     int k_c = k_n, c_c = c_n;
     uint32_t sm_c = sm_n;
     load_a(k_c, c_c, sm_c);
@@ -226,11 +226,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
     for (int ks = 0; ks < KC / 4; ++ks) load_b(step_weights(k_c, c_c), k_c, c_c, ksteps_of(c_c), ks, b[ks]);
     store_a(As, sm_c);
     advance();
-    if (FAST || have_n) load_a(have_n ? k_n : 0, c_n, sm_n);
     __syncthreads();
     int buf = 0;
 
     for (;;) {
+      // ---- gathers of the NEXT step go out first: they land during this step's matrix work and are written to the
+      //      other LDS buffer at the end of the iteration.  (Issued here rather than after the barrier so that the
+      //      conservative vmcnt(0) hipcc places on the loop back-edge never waits for a gather that was just issued.)
+      if (FAST || have_n) load_a(have_n ? k_n : 0, c_n, sm_n);
       // ---- MFMA over the current step; A operand reads run one k-step ahead of the matrix ops; each k-step's B
       //      registers are refilled for the NEXT step as soon as the matrix ops that read them are issued
       const float* a_base = As + buf * (TM_ * SA) + (wm * MR * 16 + li) * SA + lq;
@@ -274,7 +277,6 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
       c_c = c_n;
       sm_c = sm_n;
       advance();
-      if (FAST || have_n) load_a(have_n ? k_n : 0, c_n, sm_n);
       __syncthreads();
       buf ^= 1;
     }

@@ -41,13 +41,17 @@ def conv_forward(feats, weight3, plan, V_out, scale=None, shift=None, residual=N
     else:
         Vpad, perm, nbr_s, submask = plan.Vpad, plan.perm, plan.nbr_s, plan.submask
     timer = profiling.TIMER
-    t0 = timer.start() if timer is not None and timer.enabled else None
+    t0 = None
+    if timer is not None:
+        kname = profiling.conv_kernel_config(Cout, Vpad)
+        if timer.want(kname):
+            t0 = timer.start()
     call("sv_conv_fwd", ptr(feats), c_int64(feats.stride(0)), c_int(Cin), ptr(weight3), c_int(K), c_int(Cout),
          ptr(perm), ptr(nbr_s), ptr(submask), c_int64(V_out), c_int64(Vpad), ptr(scale), ptr(shift), ptr(residual),
          c_int64(residual.stride(0) if residual is not None else 0), c_int(act), c_float(slope), ptr(out),
          c_int64(out.stride(0)), stream_ptr())
     if t0 is not None:
-        timer.stop(t0, profiling.conv_kernel_config(Cout, Vpad), K, Cin, Cout, V_out,
+        timer.stop(t0, kname, K, Cin, Cout, V_out,
                    plan.pairs_device() if plan is not None else None)
     return out
 

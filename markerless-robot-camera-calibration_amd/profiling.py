@@ -41,6 +41,7 @@ class KernelTimer:
     def __init__(self, capacity=0):
         self.records = []
         self.enabled = True
+        self.only = None  # optional set of kernel names to time (None = all)
         # events are created up front: creating ~250 of them per frame inside the timed region costs milliseconds
         self._pool = [torch.cuda.Event(enable_timing=True) for _ in range(capacity)]
         self._next = 0
@@ -51,6 +52,9 @@ class KernelTimer:
             self._next += 1
             return e
         return torch.cuda.Event(enable_timing=True)
+
+    def want(self, kernel):
+        return self.enabled and (self.only is None or kernel in self.only)
 
     def start(self):
         e = self._event()
