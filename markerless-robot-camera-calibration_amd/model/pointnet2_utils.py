@@ -61,3 +61,114 @@ def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False):
     if returnfps:
         return new_xyz, new_points, grouped_xyz, fps_idx
     return new_xyz, new_points
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# set abstraction / feature propagation modules (reference :163-317).  Parameter names are the reference's
+# (mlp_convs.i = nn.Conv2d / nn.Conv1d 1x1, mlp_bns.i = BatchNorm) so its checkpoints load by key; in eval mode the
+# shared MLPs run as dense rows through the fp32-MFMA kernel with the BatchNorm folded into the epilogue.
+# ----------------------------------------------------------------------------------------------------------------------
+import numpy as np  # noqa: E402
+import torch.nn as nn  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+from .. import nn as svnn  # noqa: E402
+from .._lib import SV_ACT_RELU  # noqa: E402
+
+
+def _fold_conv_bn(conv, bn):
+    """1x1 conv (+bias) followed by BatchNorm(eval) -> W[1,Cin,Cout], scale, shift with the conv bias folded in."""
+    w = conv.weight.detach().reshape(conv.out_channels, conv.in_channels).t().contiguous().unsqueeze(0)
+    g = bn.weight.detach().float().cpu().numpy()
+    b = bn.bias.detach().float().cpu().numpy()
+    mean = bn.running_mean.detach().float().cpu().numpy()
+    var = bn.running_var.detach().float().cpu().numpy()
+    scale = (g / np.sqrt(var + np.float32(bn.eps))).astype(np.float32)
+    cb = conv.bias.detach().float().cpu().numpy() if conv.bias is not None else np.zeros_like(mean)
+    shift = (b + (cb - mean) * scale).astype(np.float32)
+    dev = conv.weight.device
+    return w, torch.from_numpy(scale).to(dev), torch.from_numpy(shift).to(dev)
+
+
+def _mlp_rows(rows, convs, bns):
+    """rows [R, Cin] -> relu(bn(conv(.))) stack, one fused launch per layer."""
+    for conv, bn in zip(convs, bns):
+        w, scale, shift = _fold_conv_bn(conv, bn)
+        rows = svnn.conv_forward(rows, w, None, rows.shape[0], scale, shift, None, SV_ACT_RELU)
+    return rows
+
+
+def sample_and_group_all(xyz, points):
+    B, N, C = xyz.shape
+    new_xyz = torch.zeros(B, 1, C, device=xyz.device)
+    grouped = xyz.view(B, 1, N, C)
+    new_points = grouped if points is None else torch.cat([grouped, points.view(B, 1, N, -1)], dim=-1)
+    return new_xyz, new_points
+
+
+class PointNetSetAbstraction(nn.Module):
+    def __init__(self, npoint, radius, nsample, in_channel, mlp, group_all):
+        super().__init__()
+        self.npoint, self.radius, self.nsample, self.group_all = npoint, radius, nsample, group_all
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last = in_channel
+        for out in mlp:
+            self.mlp_convs.append(nn.Conv2d(last, out, 1))
+            self.mlp_bns.append(nn.BatchNorm2d(out))
+            last = out
+
+    def forward(self, xyz, points):
+        """xyz [B,3,N], points [B,D,N] -> new_xyz [B,3,S], new_points [B,D',S]."""
+        xyz = xyz.permute(0, 2, 1)
+        if points is not None:
+            points = points.permute(0, 2, 1)
+        if self.group_all:
+            new_xyz, new_points = sample_and_group_all(xyz, points)
+        else:
+            new_xyz, new_points = sample_and_group(self.npoint, self.radius, self.nsample, xyz, points)
+        B, S, Kn, C = new_points.shape  # [B, npoint, nsample, C+D]
+        if self.training:
+            t = new_points.permute(0, 3, 2, 1)
+            for conv, bn in zip(self.mlp_convs, self.mlp_bns):
+                t = F.relu(bn(conv(t)))
+            pooled = torch.max(t, 2)[0]
+        else:
+            rows = _mlp_rows(new_points.reshape(B * S * Kn, C).contiguous(), self.mlp_convs, self.mlp_bns)
+            pooled = rows.view(B, S, Kn, -1).max(dim=2)[0].permute(0, 2, 1)  # [B, D', S]
+        return new_xyz.permute(0, 2, 1), pooled
+
+
+class PointNetFeaturePropagation(nn.Module):
+    def __init__(self, in_channel, mlp):
+        super().__init__()
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last = in_channel
+        for out in mlp:
+            self.mlp_convs.append(nn.Conv1d(last, out, 1))
+            self.mlp_bns.append(nn.BatchNorm1d(out))
+            last = out
+
+    def forward(self, xyz1, xyz2, points1, points2):
+        """3-NN inverse-distance interpolation of points2 (at xyz2) onto xyz1, concat points1, shared MLP."""
+        xyz1 = xyz1.permute(0, 2, 1)
+        xyz2 = xyz2.permute(0, 2, 1)
+        points2 = points2.permute(0, 2, 1)
+        B, N, _ = xyz1.shape
+        S = xyz2.shape[1]
+        if S == 1:
+            interpolated = points2.repeat(1, N, 1)
+        else:
+            dists, idx = square_distance(xyz1, xyz2).topk(3, dim=-1, largest=False, sorted=True)
+            recip = 1.0 / (dists + 1e-8)
+            weight = recip / recip.sum(dim=2, keepdim=True)
+            interpolated = torch.sum(index_points(points2, idx) * weight.view(B, N, 3, 1), dim=2)
+        new_points = interpolated if points1 is None else torch.cat([points1.permute(0, 2, 1), interpolated], dim=-1)
+        if self.training:
+            t = new_points.permute(0, 2, 1)
+            for conv, bn in zip(self.mlp_convs, self.mlp_bns):
+                t = F.relu(bn(conv(t)))
+            return t
+        rows = _mlp_rows(new_points.reshape(B * N, -1).contiguous(), self.mlp_convs, self.mlp_bns)
+        return rows.view(B, N, -1).permute(0, 2, 1)

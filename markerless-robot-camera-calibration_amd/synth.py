@@ -30,3 +30,44 @@ def gen_room(n: int, L: float = 2.4, seed: int = 0, sigma: float = 0.002):
     pts = pts @ Q.T + np.array([0.0, 0.0, L])
     rgb = rng.uniform(0.0, 1.0, size=(n, 3)) - 0.5
     return pts.astype(np.float32), rgb.astype(np.float32), axis.astype(np.int64)
+
+
+# the six constant end-effector key points of the reference (app/inference_engine.py:128-137)
+REFERENCE_KEY_POINTS = np.array([
+    [0.01982731, 0.08085986, 0.00321919],
+    [0.02171595, -0.08986182, 0.00388430],
+    [0.01288678, 0.09103118, 0.06127814],
+    [0.02079032, -0.09790908, 0.05609143],
+    [-0.00185802, 0.04654205, 0.11564558],
+    [0.00241113, -0.04262756, 0.11564558],
+])
+
+
+def random_pose(rng):
+    """(x, y, z, qw, qx, qy, qz) with a uniformly random unit quaternion and a position in front of the camera."""
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    return np.concatenate([rng.uniform(-0.5, 0.5, size=2), rng.uniform(0.6, 1.4, size=1), q])
+
+
+def quat_to_matrix(q):
+    w, x, y, z = q
+    return np.array([
+        [2 * (w * w + x * x) - 1, 2 * (x * y - w * z), 2 * (x * z + w * y)],
+        [2 * (x * y + w * z), 2 * (w * w + y * y) - 1, 2 * (y * z - w * x)],
+        [2 * (x * z - w * y), 2 * (y * z + w * x), 2 * (w * w + z * z) - 1],
+    ])
+
+
+def gen_ee_crop(seed, n=4096, kp_noise=0.001):
+    """Cfg-3 end-effector crop: n points in a 0.10 x 0.22 x 0.13 m box at a seeded pose, and the six
+    key points = REFERENCE_KEY_POINTS moved by that pose + N(0, 1 mm).
+    Returns (points float32[n,3], rgb float32[n,3], pose float64[7], key_points float64[6,3])."""
+    rng = np.random.default_rng(10_000 + seed)
+    pose = random_pose(rng)
+    R = quat_to_matrix(pose[3:])
+    local = rng.uniform(-0.5, 0.5, size=(n, 3)) * np.array([0.10, 0.22, 0.13]) + np.array([0.0, 0.0, 0.06])
+    pts = local @ R.T + pose[:3]
+    rgb = rng.uniform(0.0, 1.0, size=(n, 3)) - 0.5
+    kps = REFERENCE_KEY_POINTS @ R.T + pose[:3] + rng.normal(0.0, kp_noise, size=(6, 3))
+    return pts.astype(np.float32), rgb.astype(np.float32), pose, kps

@@ -23,3 +23,34 @@ def get_pred_center(out, coords, ee_r=0.03, q=None):
     """mean of the 8 highest-vote points (utils/output.py:45-64, without the optional quaternion offset)."""
     sel = out[:, 1].sort(descending=True)[1][:8]
     return np.asarray(coords)[sel.cpu().numpy()].mean(axis=0)
+
+
+class ClusterUtil:
+    """Largest single-linkage cluster of the end-effector points (utils/output.py:13-28: sklearn
+    AgglomerativeClustering(distance_threshold=0.06, linkage='single')).  Single linkage with a distance threshold
+    is exactly the connected components of the graph "distance < threshold"; computed on the host with a k-d tree
+    instead of sklearn's O(n^2) linkage matrix (stays a CPU step)."""
+
+    def __init__(self, dist=0.06, linkage="single"):
+        if linkage != "single":
+            raise NotImplementedError("only single linkage (what the reference uses)")
+        self.dist = dist
+
+    def labels(self, points):
+        from scipy.sparse import coo_matrix
+        from scipy.sparse.csgraph import connected_components
+        from scipy.spatial import cKDTree
+
+        pts = np.asarray(points, dtype=np.float64)
+        n = len(pts)
+        pairs = cKDTree(pts).query_pairs(self.dist, output_type="ndarray")
+        if len(pairs):
+            d = np.linalg.norm(pts[pairs[:, 0]] - pts[pairs[:, 1]], axis=1)
+            pairs = pairs[d < self.dist]  # sklearn merges while the linkage distance is < threshold
+        g = coo_matrix((np.ones(len(pairs)), (pairs[:, 0], pairs[:, 1])), shape=(n, n))
+        return connected_components(g, directed=False)[1]
+
+    def get_largest_cluster(self, points):
+        labels = self.labels(points)
+        unique, counts = np.unique(labels, return_counts=True)
+        return np.where(labels == unique[counts.argmax()])[0]

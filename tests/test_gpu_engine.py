@@ -1,0 +1,190 @@
+"""Engine-level behaviour on the GPU: the InferenceEngine mirror, PointNet2SSG on HIP sampling/grouping + MFMA MLPs,
+batched frames (the training-format batch column, Cfg-3) and the two-stream frame pipeline."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _randomize_bn(model, seed):
+    g = torch.Generator().manual_seed(seed)
+    for m in model.modules():
+        if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            with torch.no_grad():
+                m.weight.copy_(torch.rand(m.num_features, generator=g) * 0.5 + 0.75)
+                m.bias.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+                m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.num_features, generator=g) * 0.5 + 0.75)
+
+
+def test_set_abstraction_and_propagation_match_torch(gpu):
+    """eval path (HIP FPS / ball query, folded BN, MFMA rows) vs the plain torch ops the reference uses
+    (model/pointnet2_utils.py:178-204, :278-317) on the same sampled groups.  fp32 tolerance 1e-4."""
+    from mrcc_amd.model import pointnet2_utils as P2
+
+    torch.manual_seed(0)
+    sa = P2.PointNetSetAbstraction(64, 0.4, 16, 6 + 3, [16, 16, 32], False).to(gpu).eval()
+    _randomize_bn(sa, 1)
+    xyz = torch.rand(2, 3, 500, device=gpu) - 0.5
+    pts = torch.randn(2, 6, 500, device=gpu)
+    torch.manual_seed(5)
+    new_xyz, new_pts = sa(xyz, pts)
+    # torch restatement on identical groups (same FPS seed)
+    torch.manual_seed(5)
+    nx, grouped = P2.sample_and_group(64, 0.4, 16, xyz.permute(0, 2, 1), pts.permute(0, 2, 1))
+    t = grouped.permute(0, 3, 2, 1)
+    for conv, bn in zip(sa.mlp_convs, sa.mlp_bns):
+        t = F.relu(bn(conv(t)))
+    want = torch.max(t, 2)[0]
+    assert torch.equal(new_xyz, nx.permute(0, 2, 1))
+    assert (new_pts - want).abs().max().item() < 1e-4
+    fp = P2.PointNetFeaturePropagation(32 + 6, [32, 16]).to(gpu).eval()
+    _randomize_bn(fp, 2)
+    got = fp(xyz, new_xyz, pts, new_pts)
+    # reference formulation: full sort, first three
+    x1, x2 = xyz.permute(0, 2, 1), new_xyz.permute(0, 2, 1)
+    d, idx = P2.square_distance(x1, x2).sort(dim=-1)
+    d, idx = d[:, :, :3], idx[:, :, :3]
+    w = 1.0 / (d + 1e-8)
+    w = w / w.sum(dim=2, keepdim=True)
+    interp = torch.sum(P2.index_points(new_pts.permute(0, 2, 1), idx) * w.view(2, 500, 3, 1), dim=2)
+    t = torch.cat([pts.permute(0, 2, 1), interp], dim=-1).permute(0, 2, 1)
+    for conv, bn in zip(fp.mlp_convs, fp.mlp_bns):
+        t = F.relu(bn(conv(t)))
+    assert (got - t).abs().max().item() < 1e-4
+
+
+def test_pointnet2_ssg_forward(gpu):
+    from mrcc_amd.model.pointnet2 import PointNet2SSG
+
+    torch.manual_seed(0)
+    net = PointNet2SSG(num_classes=6, in_channels=6).to(gpu).eval()
+    x = torch.cat([torch.rand(1, 3, 2048, device=gpu) * 0.2, torch.rand(1, 3, 2048, device=gpu) - 0.5], dim=1)
+    with torch.no_grad():
+        logits, l4 = net(x)
+    assert logits.shape == (1, 2048, 6) and l4.shape == (1, 512, 16) and torch.isfinite(logits).all()
+    assert "sa1.mlp_convs.0.weight" in net.state_dict() and "fp1.mlp_bns.2.running_var" in net.state_dict()
+
+
+def test_batched_frames_equal_single_frames(gpu):
+    """Cfg-3 format: B frames in one sparse tensor (batch index in column 0, data/alivev2.py:358-383).  Frames never
+    interact, so each frame's logits must be BIT-identical to running it alone."""
+    import mrcc_amd
+    from mrcc_amd import MinkowskiEngine as ME
+    from mrcc_amd.model.backbone.minkunet import MinkUNet14A
+
+    torch.manual_seed(3)
+    net = MinkUNet14A(3, 8).to(gpu).eval()
+    _randomize_bn(net, 4)
+    frames = [mrcc_amd.synth.gen_room(3000 + 400 * b, 0.5, 30 + b) for b in range(4)]
+    with torch.no_grad():
+        singles = []
+        for pts, rgb, _ in frames:
+            c = torch.from_numpy(np.concatenate([np.zeros((len(pts), 1), np.float32), pts * 50], axis=1))
+            f = ME.TensorField(torch.from_numpy(rgb), c, device=gpu)
+            singles.append(net(f.sparse()).slice(f).F)
+        coords = ME.utils.batched_coordinates([torch.from_numpy(p * np.float32(50)) for p, _, _ in frames],
+                                              dtype=torch.float32)
+        feats = torch.from_numpy(np.concatenate([r for _, r, _ in frames]))
+        fb = ME.TensorField(feats, coords, device=gpu)
+        out = net(fb.sparse()).slice(fb).F
+    start = 0
+    for s in singles:
+        assert torch.equal(out[start:start + len(s)], s)
+        start += len(s)
+
+
+def test_inference_engine_pipeline(gpu, oracle):
+    import mrcc_amd
+    from mrcc_amd.app.dto import PointCloudDTO, ResultDTO
+    from mrcc_amd.app.inference_engine import InferenceEngine
+    from mrcc_amd.utils.config import Config
+
+    Config.reset()
+    Config().update({"INFERENCE": {"SEGMENTATION": {"scale": 50}, "ROTATION": {"scale": 100},
+                                   "KEY_POINTS": {"scale": 100, "conf_threshold": 0.0},
+                                   "ee_point_counts_threshold": 64, "SANITY": {"min_num_of_ee_points": 64}}})
+    try:
+        eng = InferenceEngine(allow_random_init=True, seed=7)
+        assert eng.pred_enabled
+        _randomize_bn(eng._segmentation_model, 8)
+        pts, rgb, _ = mrcc_amd.synth.gen_room(5000, 0.5, 11)
+        rgb01 = rgb + 0.5
+        seg = eng.predict_segmentation(pts, rgb)
+        assert seg.shape == (5000,) and set(np.unique(seg)) <= {0, 1, 2}
+        # same labels as the oracle graph + the same largest-cluster rule
+        sd = {k: v.cpu() for k, v in eng._segmentation_model.state_dict().items()}
+        ref = oracle.predict_segmentation(sd, pts, rgb, 50)["label"].copy()
+        ee = np.where(ref == 2)[0]
+        ref[ee] = 1
+        if len(ee) > 1:
+            ref[ee[eng.cluster_util.get_largest_cluster(pts[ee])]] = 2
+        assert np.array_equal(seg, ref)
+        # EE-crop stages on a synthetic crop
+        ee_pts, ee_rgb, pose, kps = mrcc_amd.synth.gen_ee_crop(0, n=2048)
+        q = eng.predict_rotation(ee_pts, torch.from_numpy(ee_rgb))
+        assert q.shape == (4,) and abs(np.linalg.norm(q) - 1) < 1e-5
+        pos, off = eng.predict_translation(ee_pts, None, q=q)
+        assert pos.shape == (3,) and off.shape == (3,)
+        with pytest.raises(ValueError):
+            eng.predict_translation(ee_pts, None, q=None)
+        kp_coords, kp_classes, probs = eng.predict_key_points(ee_pts, torch.from_numpy(ee_rgb))
+        assert len(kp_coords) == len(kp_classes) <= 6
+        # Kabsch from the ground-truth key points recovers the crop's pose (1 mm key-point noise)
+        kp_pose = eng.predict_pose_from_kp(kps, np.arange(6))
+        assert np.abs(kp_pose[:3] - pose[:3]).max() < 5e-3
+        assert min(np.abs(kp_pose[3:] - pose[3:]).max(), np.abs(kp_pose[3:] + pose[3:]).max()) < 5e-2
+        Ro, to = oracle.get_rigid_transform_3D(eng.reference_key_points, kps)
+        assert np.abs(kp_pose[:3] - to).max() < 1e-9
+        assert eng.predict_pose_from_kp(kps[:3], np.arange(3)) is None
+        # full predict(): returns a ResultDTO whatever the (random-weight) segmentation says
+        res = eng.predict(PointCloudDTO(points=pts, rgb=rgb01, ee2base_pose=np.array([0.1, 0, 0.5, 1.0, 0, 0, 0])))
+        assert isinstance(res, ResultDTO) and res.segmentation.shape == (5000,)
+        # calibration averaging vs the oracle's restatement of utils/calibration.py
+        rng = np.random.default_rng(0)
+        dtos = []
+        for i in range(5):
+            p = np.concatenate([pose[:3] + rng.normal(0, 0.01, 3), pose[3:] + rng.normal(0, 0.01, 4)])
+            p[3:] /= np.linalg.norm(p[3:])
+            dtos.append(ResultDTO(segmentation=None, ee_pose=p, base_pose=p, key_points_pose=p,
+                                  key_points_base_pose=p, is_confident=True))
+        cal = eng.calibrate({"pos1": dtos})
+        want = oracle.compute_poses_average(np.array([d.base_pose for d in dtos], dtype=np.float32))
+        assert np.abs(cal.base_pose[:3] - want[:3]).max() < 1e-6
+        assert min(np.abs(cal.base_pose[3:] - want[3:]).max(), np.abs(cal.base_pose[3:] + want[3:]).max()) < 1e-6
+        assert cal.pose_camera_link.shape == (7,)
+    finally:
+        Config.reset()
+
+
+def test_frame_pipeline_matches_direct_path(gpu):
+    import mrcc_amd
+    from mrcc_amd import MinkowskiEngine as ME
+    from mrcc_amd.app.pipeline import FramePipeline
+    from mrcc_amd.model.backbone.minkunet import MinkUNet14A
+
+    torch.manual_seed(1)
+    net = MinkUNet14A(3, 4).to(gpu).eval()
+    frames = []
+    for s in range(3):
+        pts, rgb, _ = mrcc_amd.synth.gen_room(4000, 0.5, 40 + s)
+        c = torch.from_numpy(np.concatenate([np.zeros((len(pts), 1), np.float32), pts * 50], axis=1)).to(gpu)
+        frames.append((c, torch.from_numpy(rgb).to(gpu)))
+    pipe = FramePipeline(gpu, levels=4)
+    with torch.no_grad():
+        direct = []
+        for c, f in frames:
+            fld = ME.TensorField(f, c, device=gpu)
+            direct.append(net(fld.sparse()).slice_argmax(fld)[0].clone())
+        nxt = pipe.prepare(*frames[0])
+        got = []
+        for i in range(3):
+            cur = nxt
+            got.append(pipe.run(cur, lambda x, fld: net(x).slice_argmax(fld)[0]))
+            if i + 1 < 3:
+                nxt = pipe.prepare(*frames[i + 1])
+        pipe.drain()
+    for a, b in zip(direct, got):
+        assert torch.equal(a, b)
