@@ -126,13 +126,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("MRCC_DIST_BACKEND", "nccl")  # "gloo" = rehearsal with several ranks on one GPU
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    device = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+    device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
     mrcc_amd._lib.load()
 
@@ -179,7 +184,7 @@ def main():
 
     h = hist.cpu().numpy()
     agg = gather_metrics({"frames": args.steps, "elapsed": elapsed, "confusion": np.diag(h), "seed_sum": voxels},
-                         device=device)
+                         device=device if backend == "nccl" else "cpu")
     t_max = agg["elapsed_max"]
     total_frames = float(agg["frames"])
     voxels_per_frame = voxels // max(args.steps, 1)
