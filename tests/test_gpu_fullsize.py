@@ -1,0 +1,121 @@
+"""Full BASELINE sizes (Cfg-2: 200k pts / 2 cm, Cfg-5: 500k pts / 1 cm) where the oracle is too slow: size-independent
+properties — voxelisation laws, duplicate-frame equality (frames in a batch never interact), linearity of the conv,
+plan invariants — plus the secondary backbones (AliveUNet, vote head)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _coords(pts, scale, b=0):
+    return np.concatenate([np.full((len(pts), 1), b, np.float32), pts * np.float32(scale)], axis=1)
+
+
+@pytest.mark.parametrize("n,scale,expect_v", [(200_000, 50, (85_000, 92_000)), (500_000, 100, (290_000, 320_000))])
+def test_fullsize_voxelise_and_maps(gpu, n, scale, expect_v):
+    import mrcc_amd
+    from mrcc_amd import MinkowskiEngine as ME
+
+    pts, rgb, _ = mrcc_amd.synth.gen_room(n, 2.4, 0)
+    c4 = _coords(pts, scale)
+    field = ME.TensorField(torch.from_numpy(rgb), torch.from_numpy(c4), device=gpu)
+    x = field.sparse()
+    V = x.F.shape[0]
+    assert expect_v[0] < V < expect_v[1]  # 88 102 / 305 659 for its generator
+    keys = x.coordinate_map.keys.cpu().numpy().view(np.uint64)
+    assert np.all(keys[1:] > keys[:-1])  # canonical, unique
+    inv = field.inverse_mapping.cpu().numpy()
+    vc = x.C.cpu().numpy()
+    assert np.array_equal(vc[inv][:, 1:], np.floor(c4[:, 1:]).astype(np.int32))  # every point in floor(coord)
+    cnt = np.bincount(inv, minlength=V)
+    assert cnt.min() >= 1 and cnt.sum() == n
+    # feature mean against a float64 scatter-add
+    sums = np.zeros((V, 3))
+    np.add.at(sums, inv, rgb.astype(np.float64))
+    assert np.abs(x.F.cpu().numpy() - sums / cnt[:, None]).max() < 1e-5
+    # pyramid + plan invariants
+    cm = x.coordinate_manager
+    prev = V
+    for level in range(4):
+        ts = 2 ** level
+        plan = cm.plan_k3(ts)
+        perm = plan.perm.cpu().numpy()
+        valid = perm >= 0
+        assert valid.sum() == plan.V_out == prev and np.array_equal(np.sort(perm[valid]), np.arange(prev))
+        nbr = plan.nbr_s.cpu().numpy()
+        assert np.array_equal(nbr[13][valid], perm[valid])  # centre offset = the voxel itself
+        assert nbr.max() < prev
+        # symmetry of the 3x3x3 map: o --k--> i  implies  i --(26-k)--> o
+        k = 5
+        src = perm[valid]
+        dst = nbr[k][valid]
+        has = dst >= 0
+        back = np.full(prev, -1, np.int64)
+        back[src] = nbr[26 - k][valid]
+        assert np.array_equal(back[dst[has]], src[has])
+        down = cm.plan_down(ts)
+        prev = down.V_out
+        assert down.num_pairs() == plan.V_out  # every fine voxel has exactly one parent
+        up = cm.plan_up(2 * ts)
+        assert up.num_pairs() == plan.V_out and up.V_out == plan.V_out
+
+
+def test_fullsize_duplicate_frames_and_linearity(gpu):
+    """Cfg-2 cloud twice in one batch: bit-identical logits per copy, and equal to the single-frame run."""
+    import mrcc_amd
+    from mrcc_amd import MinkowskiEngine as ME
+    from mrcc_amd import nn as svnn
+    from mrcc_amd.model.backbone.minkunet import MinkUNet14A
+
+    torch.manual_seed(0)
+    net = MinkUNet14A(3, 16).to(gpu).eval()
+    pts, rgb, _ = mrcc_amd.synth.gen_room(200_000, 2.4, 0)
+    with torch.no_grad():
+        f1 = ME.TensorField(torch.from_numpy(rgb), torch.from_numpy(_coords(pts, 50)), device=gpu)
+        single = net(f1.sparse())
+        c2 = np.concatenate([_coords(pts, 50, 0), _coords(pts, 50, 1)])
+        f2 = ME.TensorField(torch.from_numpy(np.concatenate([rgb, rgb])), torch.from_numpy(c2), device=gpu)
+        x2 = f2.sparse()
+        both = net(x2)
+        V = single.F.shape[0]
+        assert both.F.shape[0] == 2 * V
+        assert torch.equal(both.F[:V], single.F) and torch.equal(both.F[V:], single.F)
+        l1, _ = single.slice_argmax(f1)
+        l2, _ = both.slice_argmax(f2)
+        assert torch.equal(l2[:200_000], l1) and torch.equal(l2[200_000:], l1)
+        # linearity of a bias-free sparse conv at full size: conv(2x - 3y) == 2 conv(x) - 3 conv(y) (fp32 tolerance)
+        cm = single.coordinate_manager
+        plan = cm.plan_k3(1)
+        a = torch.randn(V, 32, device=gpu)
+        b = torch.randn(V, 32, device=gpu)
+        W = torch.randn(27, 32, 64, device=gpu) * 0.1
+        lhs = svnn.conv_forward(2 * a - 3 * b, W, plan, V)
+        rhs = 2 * svnn.conv_forward(a, W, plan, V) - 3 * svnn.conv_forward(b, W, plan, V)
+        assert (lhs - rhs).abs().max().item() < 1e-3
+
+
+def test_alive_unet_and_vote_head(gpu):
+    import mrcc_amd
+    from mrcc_amd import MinkowskiEngine as ME
+    from mrcc_amd.model.backbone.aliveunet import make_alive_unet
+    from mrcc_amd.model.robotnet_vote import RobotNetVote
+
+    pts, rgb, _ = mrcc_amd.synth.gen_room(30_000, 1.2, 3)
+    with torch.no_grad():
+        f = ME.TensorField(torch.from_numpy(rgb), torch.from_numpy(_coords(pts, 100)), device=gpu)
+        x = f.sparse()
+        torch.manual_seed(0)
+        alive = make_alive_unet(m=16, block_reps=1, bottleneck=False)(3, 8).to(gpu).eval()
+        out = alive(x)  # 7 levels down to tensor stride 128 and back; returns block14's output (no final conv)
+        assert out.tensor_stride == 1 and out.F.shape == (x.F.shape[0], 16) and torch.isfinite(out.F).all()
+        assert sorted(x.coordinate_manager.maps) == [1, 2, 4, 8, 16, 32, 64, 128]
+        vote = RobotNetVote(3).to(gpu).eval()
+        v = vote(x)
+        assert v.F.shape == (x.F.shape[0], 2)
+        # reference post-op for votes: top-8 mean (utils/output.py:45-64)
+        from mrcc_amd.utils.output import get_pred_center
+
+        pf = v.slice(f).F
+        centre = get_pred_center(pf, pts)
+        assert centre.shape == (3,) and np.isfinite(centre).all()
