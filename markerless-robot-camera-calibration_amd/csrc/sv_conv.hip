@@ -13,6 +13,7 @@
 // Numerics: every output element is ONE f32 fma chain over (k ascending, c ascending) — the MFMA is a k-ordered
 // fmaf chain (MI355X guide §3) — so results are bitwise reproducible and match oracle/sv_oracle.c exactly.
 // A missing neighbour contributes fma(0, w, acc) = acc.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "sv_common.h"
@@ -50,7 +51,11 @@ struct ConvParams {
 constexpr int PLAN_TILE = SV_TILE_ROWS;  // plans (perm / nbr_s / submask) are laid out in 128-row tiles
 // input channels per pipeline step: short tiles (used on small pyramid levels, where a launch is bound by the latency
 // of a tile's sequential step chain) take wider chunks, i.e. fewer barriers / gather round trips per tile
-constexpr int chunk_for(int tm) { return tm <= 16 ? 128 : (tm <= 32 ? 64 : 32); }
+constexpr int chunk_for(int tm, int waves_n) {
+  if (waves_n == 1) return tm <= 64 ? 128 : 64;  // tall-narrow tiles (small levels): few, fat steps
+  if (waves_n == 2) return tm <= 32 ? 128 : (tm <= 64 ? 64 : 32);
+  return tm <= 16 ? 128 : (tm <= 32 ? 64 : 32);
+}
 
 // Workgroup = 4 waves.  Tile = TM_ output rows (mask-sorted plan order) x TN output channels.
 //   WAVES_N waves split the columns (NT 16-wide MFMA column tiles each), WAVES_M = 4 / WAVES_N split the rows.
@@ -63,7 +68,7 @@ struct ConvCfg {
   static constexpr int WAVES_M = 4 / WAVES_N;
   static constexpr int MR = TM_ / WAVES_M / 16;  // 16-row sub-tiles per wave
   static constexpr int TN = WAVES_N * NT * 16;   // output channels per workgroup
-  static constexpr int KC = chunk_for(TM_);
+  static constexpr int KC = chunk_for(TM_, WAVES_N);
   static constexpr int SA = KC + 2;              // A row stride in floats: conflict-free 16x16x4 operand reads
   static constexpr int F4_PER_ROW = KC / 4;      // float4 per gathered row and step
   static constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
@@ -347,28 +352,72 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
   return SV_OK;
 }
 
-// tile height: the tallest tile that still gives the chip enough workgroups (a tile is processed sequentially:
-// K * Cin/32 steps, so few tall tiles = a latency-bound launch)
-template <int WAVES_N, int NT>
-static int launch_conv_rows(const ConvParams& p, hipStream_t stream) {
-  constexpr int TN = WAVES_N * NT * 16;
-  constexpr int MIN_TM = 16 * (4 / WAVES_N);
-  const int64_t ny = (p.Cout + TN - 1) / TN;
-  int64_t want = 1500;  // ~6 workgroups per CU: short tail, measured optimum on the Cfg-2 pyramid
-  if (const char* e = getenv("SV_CONV_MIN_WGS")) want = atoll(e);  // tuning knob (experiments only)
-  auto wgs = [&](int tm) { return (p.Vpad / tm) * ny; };
-  constexpr bool ALLOW_128 = !(WAVES_N == 4 && NT == 1);  // that instance runs out of registers
-  if constexpr (ALLOW_128) {
-    if (wgs(128) >= want || MIN_TM > 64) return launch_conv<128, WAVES_N, NT>(p, stream);
+// ---- instance selection ------------------------------------------------------------------------------------------
+// A tile is processed sequentially (K * Cin / KC steps) and streams K*Cin*TN weights + its gathered rows through one CU,
+// so the choice trades per-CU cache bandwidth (tall tiles, few column slices) against parallelism / tail (many tiles).
+// Candidates are listed from least to most traffic; the first one that puts `want` workgroups on the chip wins,
+// otherwise the one with the most workgroups.
+struct Candidate {
+  int tm, wn, nt;
+  int64_t want;  // chosen when it yields at least this many workgroups (measured on the Cfg-2 pyramid, profiles/)
+};
+
+template <int TM_, int WAVES_N, int NT>
+static bool try_launch(const Candidate& c, const ConvParams& p, hipStream_t stream, int& rc) {
+  if (c.tm == TM_ && c.wn == WAVES_N && c.nt == NT) {
+    rc = launch_conv<TM_, WAVES_N, NT>(p, stream);
+    return true;
   }
-  if constexpr (MIN_TM <= 64) {
-    if (wgs(64) >= want || MIN_TM > 32) return launch_conv<64, WAVES_N, NT>(p, stream);
-  }
-  if constexpr (MIN_TM <= 32) {
-    if (wgs(32) >= want || MIN_TM > 16) return launch_conv<32, WAVES_N, NT>(p, stream);
-  }
-  if constexpr (MIN_TM <= 16) return launch_conv<16, WAVES_N, NT>(p, stream);
+  return false;
+}
+
+static int launch_candidate(const Candidate& c, const ConvParams& p, hipStream_t stream) {
+  int rc = SV_ERR_INVALID;
+  if (try_launch<128, 4, 3>(c, p, stream, rc) || try_launch<128, 2, 3>(c, p, stream, rc) ||
+      try_launch<128, 1, 3>(c, p, stream, rc) || try_launch<64, 4, 3>(c, p, stream, rc) ||
+      try_launch<64, 2, 3>(c, p, stream, rc) || try_launch<64, 1, 3>(c, p, stream, rc) ||
+      try_launch<32, 4, 3>(c, p, stream, rc) || try_launch<32, 2, 3>(c, p, stream, rc) ||
+      try_launch<16, 4, 3>(c, p, stream, rc) ||
+      try_launch<128, 4, 2>(c, p, stream, rc) || try_launch<128, 2, 2>(c, p, stream, rc) ||
+      try_launch<128, 1, 2>(c, p, stream, rc) || try_launch<64, 4, 2>(c, p, stream, rc) ||
+      try_launch<64, 2, 2>(c, p, stream, rc) || try_launch<64, 1, 2>(c, p, stream, rc) ||
+      try_launch<32, 4, 2>(c, p, stream, rc) || try_launch<32, 2, 2>(c, p, stream, rc) ||
+      try_launch<16, 4, 2>(c, p, stream, rc) ||
+      try_launch<64, 4, 1>(c, p, stream, rc) || try_launch<32, 4, 1>(c, p, stream, rc) ||
+      try_launch<16, 4, 1>(c, p, stream, rc) || try_launch<128, 2, 1>(c, p, stream, rc) ||
+      try_launch<64, 2, 1>(c, p, stream, rc) || try_launch<32, 2, 1>(c, p, stream, rc) ||
+      try_launch<128, 1, 1>(c, p, stream, rc) || try_launch<64, 1, 1>(c, p, stream, rc))
+    return rc;
+  set_error("sv_conv_fwd: no kernel instance <%d,%d,%d>", c.tm, c.wn, c.nt);
   return SV_ERR_INVALID;
+}
+
+static int64_t candidate_wgs(const Candidate& c, const ConvParams& p) {
+  const int tn = c.wn * c.nt * 16;
+  return (p.Vpad / c.tm) * ((p.Cout + tn - 1) / tn);
+}
+
+static int select_and_launch(const ConvParams& p, hipStream_t stream) {
+  static const Candidate wide3[] = {{64, 4, 3, 2500}, {32, 4, 3, 1500}, {32, 2, 3, 0}};
+  static const Candidate wide2[] = {{128, 4, 2, 1300}, {64, 4, 2, 1500}, {32, 4, 2, 1500}, {32, 2, 2, 0}};
+  static const Candidate c64[] = {{64, 4, 1, 1500}, {32, 4, 1, 1500}, {16, 4, 1, 0}};
+  static const Candidate c32[] = {{128, 2, 1, 1500}, {64, 2, 1, 1500}, {32, 2, 1, 0}};
+  static const Candidate c16[] = {{128, 1, 1, 1500}, {64, 1, 1, 0}};
+  const Candidate* list;
+  int n;
+  const int Cout = p.Cout;
+  if (Cout > 128 && (Cout % 192 == 0 || Cout % 96 == 0 || Cout > 2048)) { list = wide3; n = 3; }
+  else if (Cout > 64) { list = wide2; n = 4; }
+  else if (Cout > 32) { list = c64; n = 3; }
+  else if (Cout > 16) { list = c32; n = 3; }
+  else { list = c16; n = 2; }
+  if (const char* f = getenv("SV_CONV_FORCE")) {  // "tm,wn,nt": experiments only
+    Candidate c = {0, 0, 0, 0};
+    if (sscanf(f, "%d,%d,%d", &c.tm, &c.wn, &c.nt) == 3 && c.nt == list[0].nt) return launch_candidate(c, p, stream);
+  }
+  for (int i = 0; i < n; ++i)
+    if (candidate_wgs(list[i], p) >= list[i].want) return launch_candidate(list[i], p, stream);
+  return launch_candidate(list[n - 1], p, stream);
 }
 
 }  // namespace sv
@@ -399,13 +448,5 @@ extern "C" int sv_conv_fwd(const float* in, int64_t in_ld, int Cin, const float*
   p.vec_b = (Cout % 4 == 0) && (((uintptr_t)W & 15) == 0);
   p.ntiles = 0;
   p.ny = 0;
-  if (Cout > 128) {
-    // 192-wide tiles waste least for 384; 128-wide for 256 / 1024 / 2048
-    if (Cout % 192 == 0 || Cout > 2048) return launch_conv_rows<4, 3>(p, stream);
-    return launch_conv_rows<4, 2>(p, stream);
-  }
-  if (Cout > 64) return launch_conv_rows<4, 2>(p, stream);
-  if (Cout > 32) return launch_conv_rows<4, 1>(p, stream);
-  if (Cout > 16) return launch_conv_rows<2, 1>(p, stream);
-  return launch_conv_rows<1, 1>(p, stream);
+  return select_and_launch(p, stream);
 }

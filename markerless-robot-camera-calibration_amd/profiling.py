@@ -9,31 +9,33 @@ import torch
 TIMER = None  # set by bench.py
 
 
+_CANDIDATES = {
+    "wide3": [(64, 4, 3, 2500), (32, 4, 3, 1500), (32, 2, 3, 0)],
+    "wide2": [(128, 4, 2, 1300), (64, 4, 2, 1500), (32, 4, 2, 1500), (32, 2, 2, 0)],
+    "c64": [(64, 4, 1, 1500), (32, 4, 1, 1500), (16, 4, 1, 0)],
+    "c32": [(128, 2, 1, 1500), (64, 2, 1, 1500), (32, 2, 1, 0)],
+    "c16": [(128, 1, 1, 1500), (64, 1, 1, 0)],
+}
+
+
 def conv_kernel_config(Cout, Vpad):
-    """Mirror of the dispatch in csrc/sv_conv.hip (sv_conv_fwd + launch_conv_rows) -> template instance name as
-    rocprofv3 prints it: conv_fwd_kernel<TM, WAVES_N, NT>."""
-    if Cout > 128:
-        wn, nt = (4, 3) if (Cout % 192 == 0 or Cout > 2048) else (4, 2)
+    """Mirror of select_and_launch() in csrc/sv_conv.hip -> template instance name as rocprofv3 prints it:
+    conv_fwd_kernel<TM, WAVES_N, NT>."""
+    if Cout > 128 and (Cout % 192 == 0 or Cout % 96 == 0 or Cout > 2048):
+        cands = _CANDIDATES["wide3"]
     elif Cout > 64:
-        wn, nt = 4, 2
+        cands = _CANDIDATES["wide2"]
     elif Cout > 32:
-        wn, nt = 4, 1
+        cands = _CANDIDATES["c64"]
     elif Cout > 16:
-        wn, nt = 2, 1
+        cands = _CANDIDATES["c32"]
     else:
-        wn, nt = 1, 1
-    tn = wn * nt * 16
-    min_tm = 16 * (4 // wn)
-    ny = (Cout + tn - 1) // tn
-    tm = min_tm
-    for cand in (128, 64, 32, 16):
-        if cand == 128 and (wn, nt) == (4, 1):
-            continue
-        if cand < min_tm:
-            break
-        tm = cand
-        if (Vpad // cand) * ny >= 1500:
-            break
+        cands = _CANDIDATES["c16"]
+    for tm, wn, nt, want in cands:
+        tn = wn * nt * 16
+        if (Vpad // tm) * ((Cout + tn - 1) // tn) >= want:
+            return f"conv_fwd_kernel<{tm}, {wn}, {nt}>"
+    tm, wn, nt, _ = cands[-1]
     return f"conv_fwd_kernel<{tm}, {wn}, {nt}>"
 
 
