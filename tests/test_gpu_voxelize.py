@@ -124,3 +124,23 @@ def test_stride_and_kernel_maps_match_oracle(gpu, oracle, n, L, scale):
         assert np.array_equal(unsort(cm.plan_k3(ts)), frame.k3(ts))
         assert np.array_equal(unsort(cm.plan_down(ts)), frame.kdown(ts))
         assert np.array_equal(unsort(cm.plan_up(2 * ts)), frame.kup(2 * ts))
+
+
+def test_empty_and_single_point_inputs_run_through_a_network(gpu):
+    """ragged / degenerate inputs: an empty cloud and a one-point cloud must flow through voxelise -> U-Net -> slice."""
+    from mrcc_amd import MinkowskiEngine as ME
+    from mrcc_amd.model.backbone.minkunet import MinkUNet14A
+
+    torch.manual_seed(0)
+    net = MinkUNet14A(3, 5).to(gpu).eval()
+    with torch.no_grad():
+        for n in (0, 1, 17):
+            pts = np.random.default_rng(n).uniform(-0.3, 0.3, size=(n, 3)).astype(np.float32)
+            rgb = np.zeros((n, 3), np.float32) + 0.25
+            field, _ = _field(ME, pts, rgb, 50, gpu)
+            x = field.sparse()
+            assert x.F.shape[0] <= n
+            out = net(x)
+            assert out.F.shape == (x.F.shape[0], 5)
+            label, conf = out.slice_argmax(field)
+            assert label.shape == (n,) and (n == 0 or torch.isfinite(out.F).all())

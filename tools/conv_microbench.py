@@ -21,11 +21,18 @@ ap.add_argument("--level", type=int, default=0)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--points", type=int, default=200000)
 ap.add_argument("--kind", default="k3")
+ap.add_argument("--cube", type=int, default=0, help="solid cube of this edge length (voxels) instead of the room cloud")
 args = ap.parse_args()
 
 dev = torch.device("cuda:0")
-pts, rgb, _ = mrcc_amd.synth.gen_room(args.points, 2.4, 0)
-coords4 = np.concatenate([np.zeros((len(pts), 1), np.float32), pts * np.float32(50)], axis=1)
+if args.cube:
+    g = np.arange(args.cube, dtype=np.float32) + 0.5
+    xyz = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3)
+    coords4 = np.concatenate([np.zeros((len(xyz), 1), np.float32), xyz], axis=1)
+    rgb = np.zeros((len(xyz), 3), np.float32)
+else:
+    pts, rgb, _ = mrcc_amd.synth.gen_room(args.points, 2.4, 0)
+    coords4 = np.concatenate([np.zeros((len(pts), 1), np.float32), pts * np.float32(50)], axis=1)
 x = ME.TensorField(torch.from_numpy(rgb), torch.from_numpy(coords4), device=dev).sparse()
 cm = x.coordinate_manager
 ts = 2 ** args.level
