@@ -118,11 +118,13 @@ int sv_kernel_map_up(const uint64_t* keys_fine, const int32_t* parent, int64_t V
  * perm:    int32[Vpad]        output row handled at sorted position r (-1 = padding)
  * nbr_s:   int32[K][Vpad]     nbr[k][perm[r]]
  * submask: uint32[Vpad/128][K] bit s set = sub-tile s (rows 16s..16s+15 of the tile) has a neighbour at offset k
+ * tile_order: int32[Vpad/128] plan tiles sorted by work (number of active (offset, sub-tile) slots) descending: the
+ *          conv kernel dispatches its workgroups in this order (longest first) so the launch has a short tail
  * Vpad = round_up(V, 128). */
 size_t sv_plan_workspace_bytes(int64_t V);
 int sv_plan_build(const int32_t* nbr, int64_t ld, const uint32_t* mask, int K, int64_t V, void* workspace,
-                  size_t workspace_bytes, int32_t* perm, int32_t* nbr_s, uint32_t* submask, int64_t Vpad,
-                  sv_stream_t stream);
+                  size_t workspace_bytes, int32_t* perm, int32_t* nbr_s, uint32_t* submask, int32_t* tile_order,
+                  int64_t Vpad, sv_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A3/A5  sparse convolution, output stationary, fp32 MFMA, fused epilogue
@@ -134,10 +136,11 @@ int sv_plan_build(const int32_t* nbr, int64_t ld, const uint32_t* mask, int K, i
  *   y = acc * scale[n] + shift[n]  (fmaf; scale NULL = 1, shift NULL = 0)   BN(eval) folded / bias
  *   y += residual[o][n]            (residual NULL = none)
  *   out[o][n] = act(y)
- * perm/nbr_s/submask NULL = dense rows (kernel_size 1 / Linear): nbr = identity.
+ * perm/nbr_s/submask NULL = dense rows (kernel_size 1 / Linear): nbr = identity.  tile_order may be NULL.
  * ------------------------------------------------------------------------------------------- */
 int sv_conv_fwd(const float* in, int64_t in_ld, int Cin, const float* W, int K, int Cout, const int32_t* perm,
-                const int32_t* nbr_s, const uint32_t* submask, int64_t V_out, int64_t Vpad, const float* scale,
+                const int32_t* nbr_s, const uint32_t* submask, const int32_t* tile_order, int64_t V_out, int64_t Vpad,
+                const float* scale,
                 const float* shift, const float* residual, int64_t res_ld, int act, float slope, float* out,
                 int64_t out_ld, sv_stream_t stream);
 

@@ -40,11 +40,11 @@ SIGNATURES = {
     "sv_kernel_map_down": (c_int, [_P, _P, c_int64, c_int, c_int64, _P, c_int64, _P, _P]),
     "sv_kernel_map_up": (c_int, [_P, _P, c_int64, c_int, _P, c_int64, _P, _P]),
     "sv_plan_workspace_bytes": (c_size_t, [c_int64]),
-    "sv_plan_build": (c_int, [_P, c_int64, _P, c_int, c_int64, _P, c_size_t, _P, _P, _P, c_int64, _P]),
+    "sv_plan_build": (c_int, [_P, c_int64, _P, c_int, c_int64, _P, c_size_t, _P, _P, _P, _P, c_int64, _P]),
     "sv_conv_fwd": (
         c_int,
-        [_P, c_int64, c_int, _P, c_int, c_int, _P, _P, _P, c_int64, c_int64, _P, _P, _P, c_int64, c_int, c_float, _P,
-         c_int64, _P],
+        [_P, c_int64, c_int, _P, c_int, c_int, _P, _P, _P, _P, c_int64, c_int64, _P, _P, _P, c_int64, c_int, c_float,
+         _P, c_int64, _P],
     ),
     "sv_affine_act": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, _P, c_int64, c_int, c_float, _P, c_int64, _P]),
     "sv_batch_offsets": (c_int, [_P, c_int64, c_int, _P, _P]),

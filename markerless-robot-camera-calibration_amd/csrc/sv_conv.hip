@@ -32,6 +32,7 @@ struct ConvParams {
   const int32_t* perm;
   const int32_t* nbr_s;
   const uint32_t* submask;
+  const int32_t* tile_order;  // plan tiles (128 rows), longest first; NULL = reverse plan order
   int64_t V_out;
   int64_t Vpad;
   const float* scale;
@@ -97,10 +98,15 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
-  // 1-D grid, heavy tiles first: rows are mask-sorted ascending, so the tiles with the most neighbour offsets sit at the
-  // end of the plan; dispatching them first keeps the tail of the launch short (list scheduling, longest first).
+  // 1-D grid, longest tiles first (list scheduling): plan tiles are visited in the plan's tile_order (sorted by active
+  // (offset, sub-tile) slots, descending); without one, in reverse plan order (rows are sorted by neighbour key, so
+  // the tiles with the most neighbour offsets sit at the end).
   const int ny = p.ny;
-  const int tile = p.ntiles - 1 - (int)(blockIdx.x / ny);
+  constexpr int SUB_PER_PLAN_TILE = PLAN_TILE / TM_;
+  const int t_lin = (int)(blockIdx.x / ny);
+  const int t128 = t_lin / SUB_PER_PLAN_TILE;
+  const int p128 = p.tile_order ? p.tile_order[t128] : (p.ntiles / SUB_PER_PLAN_TILE - 1 - t128);
+  const int tile = p128 * SUB_PER_PLAN_TILE + (t_lin % SUB_PER_PLAN_TILE);
   const int n0 = (int)(blockIdx.x % ny) * TN;
   const int64_t row0 = (int64_t)tile * TM_;
   const int li = lane & 15, lq = lane >> 4;
@@ -425,8 +431,8 @@ static int select_and_launch(const ConvParams& p, hipStream_t stream) {
 using namespace sv;
 
 extern "C" int sv_conv_fwd(const float* in, int64_t in_ld, int Cin, const float* W, int K, int Cout,
-                           const int32_t* perm, const int32_t* nbr_s, const uint32_t* submask, int64_t V_out,
-                           int64_t Vpad, const float* scale, const float* shift, const float* residual, int64_t res_ld,
+                           const int32_t* perm, const int32_t* nbr_s, const uint32_t* submask,
+                           const int32_t* tile_order, int64_t V_out, int64_t Vpad, const float* scale, const float* shift, const float* residual, int64_t res_ld,
                            int act, float slope, float* out, int64_t out_ld, sv_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SV_CHECK_ARG(Cin > 0 && Cout > 0 && K >= 1 && K <= 32, "bad channel / kernel volume");
@@ -441,7 +447,7 @@ extern "C" int sv_conv_fwd(const float* in, int64_t in_ld, int Cin, const float*
   SV_CHECK_ARG(!residual || res_ld >= Cout, "residual stride too small");
   ConvParams p;
   p.in = in; p.in_ld = in_ld; p.Cin = Cin; p.W = W; p.K = K; p.Cout = Cout;
-  p.perm = perm; p.nbr_s = nbr_s; p.submask = submask; p.V_out = V_out; p.Vpad = Vpad;
+  p.perm = perm; p.nbr_s = nbr_s; p.submask = submask; p.tile_order = tile_order; p.V_out = V_out; p.Vpad = Vpad;
   p.scale = scale; p.shift = shift; p.residual = residual; p.res_ld = res_ld;
   p.act = act; p.slope = slope; p.out = out; p.out_ld = out_ld;
   p.vec_a = (in_ld % 4 == 0) && (Cin % 4 == 0) && (((uintptr_t)in & 15) == 0);

@@ -349,6 +349,17 @@ __global__ __launch_bounds__(128) void plan_gather_kernel(const int32_t* __restr
   }
 }
 
+// work of a plan tile = active (offset, sub-tile) slots; sort key ascending = work descending
+__global__ __launch_bounds__(256) void tile_cost_kernel(const uint32_t* __restrict__ submask, int K, int64_t tiles,
+                                                         uint32_t* __restrict__ key, int32_t* __restrict__ idx) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= tiles) return;
+  uint32_t cost = 0;
+  for (int k = 0; k < K; ++k) cost += __popc(submask[t * K + k]);
+  key[t] = 0xffffu - cost;  // cost <= 27 * 8
+  idx[t] = (int32_t)t;
+}
+
 }  // namespace sv
 
 using namespace sv;
@@ -523,12 +534,13 @@ int sv_kernel_map_up(const uint64_t* keys_fine, const int32_t* parent, int64_t V
 
 size_t sv_plan_workspace_bytes(int64_t V) {
   if (V <= 0) return 256;
-  return align_up((size_t)V * 4, 256) * 4 + align_up(sort_pairs_u32_temp_bytes(V), 256) + 4096;
+  return align_up((size_t)V * 4, 256) * 4 + align_up(sort_pairs_u32_temp_bytes(V), 256) * 2 + 8192 +
+         align_up((size_t)(V / 128 + 2) * 4, 256) * 3;
 }
 
 int sv_plan_build(const int32_t* nbr, int64_t ld, const uint32_t* mask, int K, int64_t V, void* workspace,
-                  size_t workspace_bytes, int32_t* perm, int32_t* nbr_s, uint32_t* submask, int64_t Vpad,
-                  sv_stream_t stream_) {
+                  size_t workspace_bytes, int32_t* perm, int32_t* nbr_s, uint32_t* submask, int32_t* tile_order,
+                  int64_t Vpad, sv_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SV_CHECK_ARG(K >= 1 && K <= 32, "K must be in 1..32");
   SV_CHECK_ARG(V >= 0 && ld >= V, "bad shape");
@@ -542,6 +554,12 @@ int sv_plan_build(const int32_t* nbr, int64_t ld, const uint32_t* mask, int K, i
   uint32_t* key = ws.take<uint32_t>(V);
   size_t sort_bytes = sort_pairs_u32_temp_bytes(V);
   char* sort_tmp = ws.take<char>(sort_bytes);
+  const int64_t ntiles = Vpad / SV_TILE_ROWS;
+  uint32_t* tkey = ws.take<uint32_t>(ntiles);
+  uint32_t* tkey_sorted = ws.take<uint32_t>(ntiles);
+  int32_t* tidx = ws.take<int32_t>(ntiles);
+  size_t tsort_bytes = sort_pairs_u32_temp_bytes(ntiles);
+  char* tsort_tmp = ws.take<char>(tsort_bytes);
   if (!ws.ok) {
     set_error("sv_plan_build: workspace too small");
     return SV_ERR_WORKSPACE;
@@ -557,6 +575,13 @@ int sv_plan_build(const int32_t* nbr, int64_t ld, const uint32_t* mask, int K, i
   hipLaunchKernelGGL(plan_gather_kernel, dim3((unsigned)tiles, (unsigned)K), dim3(128), 0, stream, nbr, ld, sorted_rows,
                      V, Vpad, K, perm, nbr_s, submask);
   SV_LAUNCH_CHECK();
+  if (tile_order) {
+    hipLaunchKernelGGL(tile_cost_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, submask, K,
+                       ntiles, tkey, tidx);
+    SV_LAUNCH_CHECK();
+    SV_HIP(rocprim::radix_sort_pairs((void*)tsort_tmp, tsort_bytes, tkey, tkey_sorted, tidx, tile_order,
+                                     (size_t)ntiles, 0, 16, stream));
+  }
   return SV_OK;
 }
 

@@ -37,9 +37,9 @@ def conv_forward(feats, weight3, plan, V_out, scale=None, shift=None, residual=N
         out = torch.empty((V_out, Cout), dtype=torch.float32, device=feats.device)
     if plan is None:
         Vpad = (max(V_out, 1) + _lib.SV_TILE_ROWS - 1) // _lib.SV_TILE_ROWS * _lib.SV_TILE_ROWS
-        perm = nbr_s = submask = None
+        perm = nbr_s = submask = tile_order = None
     else:
-        Vpad, perm, nbr_s, submask = plan.Vpad, plan.perm, plan.nbr_s, plan.submask
+        Vpad, perm, nbr_s, submask, tile_order = plan.Vpad, plan.perm, plan.nbr_s, plan.submask, plan.tile_order
     timer = profiling.TIMER
     t0 = None
     if timer is not None:
@@ -47,7 +47,8 @@ def conv_forward(feats, weight3, plan, V_out, scale=None, shift=None, residual=N
         if timer.want(kname):
             t0 = timer.start()
     call("sv_conv_fwd", ptr(feats), c_int64(feats.stride(0)), c_int(Cin), ptr(weight3), c_int(K), c_int(Cout),
-         ptr(perm), ptr(nbr_s), ptr(submask), c_int64(V_out), c_int64(Vpad), ptr(scale), ptr(shift), ptr(residual),
+         ptr(perm), ptr(nbr_s), ptr(submask), ptr(tile_order), c_int64(V_out), c_int64(Vpad), ptr(scale), ptr(shift),
+         ptr(residual),
          c_int64(residual.stride(0) if residual is not None else 0), c_int(act), c_float(slope), ptr(out),
          c_int64(out.stride(0)), stream_ptr())
     if t0 is not None:

@@ -66,10 +66,10 @@ class CoordinateMap:
 class ConvPlan:
     """Mask-sorted execution plan of one kernel map (include/sv_hip.h sv_plan_build)."""
 
-    __slots__ = ("perm", "nbr_s", "submask", "V_out", "Vpad", "K", "pairs")
+    __slots__ = ("perm", "nbr_s", "submask", "tile_order", "V_out", "Vpad", "K", "pairs")
 
-    def __init__(self, perm, nbr_s, submask, V_out, Vpad, K):
-        self.perm, self.nbr_s, self.submask = perm, nbr_s, submask
+    def __init__(self, perm, nbr_s, submask, tile_order, V_out, Vpad, K):
+        self.perm, self.nbr_s, self.submask, self.tile_order = perm, nbr_s, submask, tile_order
         self.V_out, self.Vpad, self.K = V_out, Vpad, K
         self.pairs = None  # number of (in,out) pairs, filled lazily for roofline accounting
 
@@ -127,9 +127,10 @@ class CoordinateManager:
         perm = torch.empty(Vpad, dtype=torch.int32, device=dev)
         nbr_s = torch.empty((K, Vpad), dtype=torch.int32, device=dev)
         submask = torch.empty((Vpad // SV_TILE_ROWS, K), dtype=torch.int32, device=dev)
+        tile_order = torch.empty(Vpad // SV_TILE_ROWS, dtype=torch.int32, device=dev)
         call("sv_plan_build", ptr(nbr), c_int64(ld), ptr(mask), c_int(K), c_int64(V_out), ptr(ws), c_size_t(ws_bytes),
-             ptr(perm), ptr(nbr_s), ptr(submask), c_int64(Vpad), stream_ptr())
-        return ConvPlan(perm, nbr_s, submask, V_out, Vpad, K)
+             ptr(perm), ptr(nbr_s), ptr(submask), ptr(tile_order), c_int64(Vpad), stream_ptr())
+        return ConvPlan(perm, nbr_s, submask, tile_order, V_out, Vpad, K)
 
     def plan_k3(self, stride, dilation=1):
         key = ("k3", stride, dilation)

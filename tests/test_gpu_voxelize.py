@@ -118,6 +118,11 @@ def test_stride_and_kernel_maps_match_oracle(gpu, oracle, n, L, scale):
         sub = (nbr_s >= 0).reshape(plan.K, plan.Vpad // 128, 8, 16).any(axis=3)  # [K, tiles, 8]
         bits = (sub * (1 << np.arange(8))).sum(axis=2).T  # [tiles, K]
         assert np.array_equal(plan.submask.cpu().numpy().astype(np.int64), bits)
+        # tile_order: a permutation of the plan tiles, work (active sub-tile slots) non-increasing
+        order = plan.tile_order.cpu().numpy()
+        assert np.array_equal(np.sort(order), np.arange(plan.Vpad // 128))
+        work = sub.sum(axis=(0, 2))[order]
+        assert np.all(np.diff(work) <= 0)
         return out
 
     for ts in (1, 2, 4):
