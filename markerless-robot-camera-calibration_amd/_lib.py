@@ -10,7 +10,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsvhip.so")
+LIB_PATH = os.environ.get("SVHIP_LIB") or os.path.join(_HERE, "libsvhip.so")  # SVHIP_LIB: kernel A/B experiments
 
 SV_ACT_NONE, SV_ACT_RELU, SV_ACT_LEAKY_RELU = 0, 1, 2
 SV_POOL_MAX, SV_POOL_AVG = 0, 1
