@@ -71,3 +71,29 @@ def gen_ee_crop(seed, n=4096, kp_noise=0.001):
     rgb = rng.uniform(0.0, 1.0, size=(n, 3)) - 0.5
     kps = REFERENCE_KEY_POINTS @ R.T + pose[:3] + rng.normal(0.0, kp_noise, size=(6, 3))
     return pts.astype(np.float32), rgb.astype(np.float32), pose, kps
+
+
+def gen_scene(seed, n_bg=40_000, n_arm=4_000, n_ee=4_096, room=2.4):
+    """A labelled robot scene for the evaluation harness (reference frame format, README.md:55-62): background room
+    (label 0), a 4 cm-radius arm cylinder from a base point to the end effector (label 1) and the EE crop (label 2) at a
+    seeded pose.  Returns dict(points, rgb in [0,1], segmentation, pose (x,y,z,qw,qx,qy,qz), key_points [6,3],
+    ee2base_pose, position)."""
+    rng = np.random.default_rng(20_000 + seed)
+    bg, _, _ = gen_room(n_bg, room, seed)
+    ee, _, pose, kps = gen_ee_crop(seed, n=n_ee)
+    base = np.array([0.0, -0.6, room * 0.6])
+    t = rng.uniform(0.0, 1.0, size=(n_arm, 1))
+    axis = pose[:3] - base
+    u = np.cross(axis, [0.0, 0.0, 1.0])
+    u /= np.linalg.norm(u)
+    v = np.cross(axis, u)
+    v /= np.linalg.norm(v)
+    ang = rng.uniform(0, 2 * np.pi, size=(n_arm, 1))
+    arm = base + t * axis + 0.04 * (np.cos(ang) * u + np.sin(ang) * v)
+    points = np.concatenate([bg, arm.astype(np.float32), ee]).astype(np.float32)
+    seg = np.concatenate([np.zeros(len(bg), np.int64), np.ones(n_arm, np.int64), np.full(len(ee), 2, np.int64)])
+    rgb = rng.uniform(0.0, 1.0, size=(len(points), 3)).astype(np.float32)
+    perm = rng.permutation(len(points))
+    ee2base = np.concatenate([rng.uniform(-0.3, 0.3, size=3), random_pose(rng)[3:]])
+    return {"points": points[perm], "rgb": rgb[perm], "segmentation": seg[perm], "pose": pose, "key_points": kps,
+            "ee2base_pose": ee2base, "position": f"p{seed % 3 + 1}"}

@@ -41,11 +41,31 @@ def compute_translational_diff(t1, t2, cm=True, method="euclidean"):
     return dist * 100 if cm else dist
 
 
-def compute_pose_metrics(gt_pose, pred_pose):
-    """utils/metrics.py:110-127 reduced to the two numbers app/test.py reports: position (m) and angle (rad) error."""
-    gt_pose, pred_pose = np.asarray(gt_pose, dtype=np.float64), np.asarray(pred_pose, dtype=np.float64)
-    return {"dist_position": float(np.linalg.norm(gt_pose[:3] - pred_pose[:3])),
-            "angle_diff": float(compute_rotational_diff(gt_pose[3:7], pred_pose[3:7], degree=False))}
+def _qmul(q, r):
+    """Hamilton product, (w, x, y, z) (utils/quaternion.py qmul_np)."""
+    w0, x0, y0, z0 = q
+    w1, x1, y1, z1 = r
+    return np.array([w0 * w1 - x0 * x1 - y0 * y1 - z0 * z1, w0 * x1 + x0 * w1 + y0 * z1 - z0 * y1,
+                     w0 * y1 - x0 * z1 + y0 * w1 + z0 * x1, w0 * z1 + x0 * y1 - y0 * x1 + z0 * w1])
+
+
+def compute_pose_metrics(gt, pred):
+    """utils/metrics.py:110-127: position error (m) and the rotation angle of gt * conj(pred) (rad, in [0, pi])."""
+    gt, pred = np.asarray(gt, dtype=np.float64), np.asarray(pred, dtype=np.float64)
+    gt_rot = gt[3:7] / np.linalg.norm(gt[3:7])
+    pred_rot = pred[3:7] / np.linalg.norm(pred[3:7])
+    q = _qmul(gt_rot, pred_rot * np.array([1.0, -1.0, -1.0, -1.0]))
+    angle = np.abs(2 * np.arctan2(np.linalg.norm(q[1:]), q[0]))
+    return {"dist_position": float(np.linalg.norm(gt[:3] - pred[:3])),
+            "angle_diff": float(min(angle, 2 * np.pi - angle))}
+
+
+def compute_kp_error(gt_coords, kp_coords, kp_classes):
+    """utils/metrics.py:130-136: mean distance between predicted key points and the ground-truth ones of their class;
+    100 when fewer than two are available."""
+    if len(gt_coords) < 2 or len(kp_coords) < 2 or len(kp_classes) < 2:
+        return 100
+    return float(np.linalg.norm(np.asarray(gt_coords)[np.asarray(kp_classes)] - np.asarray(kp_coords), axis=1).mean())
 
 
 def confusion_matrix(pred, gt, num_classes):
@@ -73,4 +93,36 @@ def segmentation_metrics_from_confusion(cm):
 
 
 def compute_segmentation_metrics(gt, pred, classes=("background", "arm", "ee")):
-    return segmentation_metrics_from_confusion(confusion_matrix(pred, gt, len(classes)))
+    """utils/metrics.py:51-107, quirks included: per class accuracy/precision/recall with precision = 1 when there is no
+    false positive (recall = 1 when no false negative); overall "accuracy" = (sensitivity + specificity) / 2 over the
+    summed one-vs-rest counts; overall precision / recall = plain means over classes.  `miou` is this build's addition
+    (BASELINE.json asks for it; the reference never computes IoU on this path)."""
+    gt = np.asarray(gt)
+    pred = np.asarray(pred)
+    n = len(gt)
+    results = {"class_results": {}}
+    precisions, recalls, ious = [], [], []
+    tp_s = tn_s = fp_s = fn_s = 0
+    for ci, cn in enumerate(classes):
+        g = gt == ci
+        p = pred == ci
+        tp = int((g & p).sum())
+        tn = int(n - (g | p).sum())
+        fp = int(p.sum()) - tp
+        fn = int(g.sum()) - tp
+        tp_s, tn_s, fp_s, fn_s = tp_s + tp, tn_s + tn, fp_s + fp, fn_s + fn
+        precision = 1 if fp == 0 else tp / (tp + fp)
+        recall = 1 if fn == 0 else tp / (tp + fn)
+        results["class_results"][cn] = {"accuracy": (tp + tn) / (tp + tn + fp + fn), "precision": precision,
+                                        "recall": recall}
+        precisions.append(precision)
+        recalls.append(recall)
+        if tp + fp + fn > 0:
+            ious.append(tp / (tp + fp + fn))
+    sensitivity = tp_s / (tp_s + fn_s)
+    specificity = tn_s / (tn_s + fp_s)
+    results["accuracy"] = (sensitivity + specificity) / 2
+    results["precision"] = float(np.mean(precisions))
+    results["recall"] = float(np.mean(recalls))
+    results["miou"] = float(np.mean(ious)) if ious else float("nan")
+    return results

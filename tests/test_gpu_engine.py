@@ -188,3 +188,33 @@ def test_frame_pipeline_matches_direct_path(gpu):
         pipe.drain()
     for a, b in zip(direct, got):
         assert torch.equal(a, b)
+
+
+def test_evaluation_harness_end_to_end(gpu):
+    """app/test.py recipe on synthetic labelled scenes with the real engine (random weights: the
+    numbers are meaningless, the flow and the metric types are what is checked) and with ground-truth segmentation."""
+    import mrcc_amd
+    from mrcc_amd.app.evaluate import TestApp
+    from mrcc_amd.app.inference_engine import InferenceEngine
+    from mrcc_amd.utils.config import Config
+
+    Config.reset()
+    Config().update({"INFERENCE": {"SEGMENTATION": {"scale": 50}, "ROTATION": {"scale": 100},
+                                   "KEY_POINTS": {"scale": 100, "conf_threshold": 0.0},
+                                   "ee_point_counts_threshold": 64, "SANITY": {"min_num_of_ee_points": 64}}})
+    try:
+        eng = InferenceEngine(allow_random_init=True, seed=3)
+        frames = [mrcc_amd.synth.gen_scene(s, n_bg=6000, n_arm=800, n_ee=1500) for s in range(3)]
+        app = TestApp(eng, evaluate_segmentation=False)  # use the ground-truth segmentation for the EE crop
+        out = app.run_tests(frames)
+        assert len(out["instances"]) == 3
+        for inst in out["instances"].values():
+            assert np.isfinite(inst["nn_ADD"]) and 0 <= inst["nn_angle_diff"] <= np.pi + 1e-9
+            assert "base_dist_position" in inst
+        assert out["calibration"] is not None
+        assert set(out["overall"]["nn_ADD"]) == {"mean", "min", "max", "median", "stdev"}
+        # with predicted segmentation the per-frame segmentation metrics appear
+        out2 = TestApp(eng, ee_point_counts_threshold=10 ** 9).run_tests(frames[:1])
+        assert out2["instances"] == {}  # every frame fails the EE-count threshold, as in app/test.py:110-113
+    finally:
+        Config.reset()

@@ -88,4 +88,6 @@ def test_segmentation_metrics_and_synth():
     pred = lab.copy()
     pred[:100] = (pred[:100] + 1) % 3
     m = M.compute_segmentation_metrics(lab, pred)
-    assert 0.8 < m["miou"] < 1.0 and abs(m["accuracy"] - 0.95) < 1e-9
+    assert 0.8 < m["miou"] < 1.0 and 0.9 < m["accuracy"] < 1.0  # reference "accuracy" = (sensitivity + specificity)/2
+    plain = M.segmentation_metrics_from_confusion(M.confusion_matrix(pred, lab, 3))
+    assert abs(plain["accuracy"] - 0.95) < 1e-9 and abs(plain["miou"] - m["miou"]) < 1e-12

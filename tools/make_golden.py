@@ -30,11 +30,6 @@ from utils import data as Dat  # noqa: E402
 import torch  # noqa: E402
 from model import pointnet2_utils as P2  # noqa: E402
 
-# the six constant key points of the end effector, app/inference_engine.py:128-137
-REFERENCE_KEY_POINTS = np.array(
-    [[0.0, 0.0, 0.0], [0.0, 0.0, 0.0], [0.0, 0.0, 0.0], [0.0, 0.0, 0.0], [0.0, 0.0, 0.0], [0.0, 0.0, 0.0]])
-
-
 def read_reference_key_points():
     import re
 
@@ -164,6 +159,38 @@ def gen_ball_query(rng):
                 nsample=np.int64(nsample), min_margin=np.float64(np.abs(d - np.float32(radius ** 2)).min()))
 
 
+def gen_metrics(rng):
+    n, B = 4000, 12
+    gts = rng.integers(0, 3, size=(B, n))
+    preds = gts.copy()
+    acc = np.zeros(B); prec = np.zeros(B); rec = np.zeros(B); cls = np.zeros((B, 3, 3))
+    for b in range(B):
+        flip = rng.random(n) < (0.02 * b)
+        preds[b, flip] = rng.integers(0, 3, size=flip.sum())
+        if b == 3:
+            preds[b, preds[b] == 2] = 1  # a class that is never predicted
+        if b == 5:
+            gts[b, gts[b] == 0] = 1  # a class absent from the ground truth
+        r = Mx.compute_segmentation_metrics(gts[b], preds[b])
+        acc[b], prec[b], rec[b] = r["accuracy"], r["precision"], r["recall"]
+        for ci, cn in enumerate(["background", "arm", "ee"]):
+            c = r["class_results"][cn]
+            cls[b, ci] = [c["accuracy"], float(c["precision"]), float(c["recall"])]
+    P = 64
+    gt_pose = np.zeros((P, 7)); pr_pose = np.zeros((P, 7)); dpos = np.zeros(P); dang = np.zeros(P)
+    for i in range(P):
+        gt_pose[i, :3] = rng.uniform(-1, 1, 3); gt_pose[i, 3:] = rand_quat(rng)
+        pr_pose[i, :3] = gt_pose[i, :3] + rng.normal(0, 0.05, 3)
+        q = gt_pose[i, 3:] + rng.normal(0, 0.1 * (1 + i % 5), 4)
+        pr_pose[i, 3:] = (q / np.linalg.norm(q)) * (1 if i % 2 else -1) * (1.0 if i % 3 else 2.5)  # sign / scale
+        r = Mx.compute_pose_metrics(gt_pose[i], pr_pose[i])
+        dpos[i], dang[i] = r["dist_position"], r["angle_diff"]
+    kp_gt = rng.uniform(-0.1, 0.1, size=(6, 3)); kp_cls = np.array([0, 2, 3, 5]); kp_pred = kp_gt[kp_cls] + rng.normal(0, 0.01, (4, 3))
+    return dict(seg_gt=gts, seg_pred=preds, seg_accuracy=acc, seg_precision=prec, seg_recall=rec, seg_class=cls,
+                gt_pose=gt_pose, pred_pose=pr_pose, dist_position=dpos, angle_diff=dang, kp_gt=kp_gt, kp_cls=kp_cls,
+                kp_pred=kp_pred, kp_error=np.float64(Mx.compute_kp_error(kp_gt, kp_pred, kp_cls)))
+
+
 def gen_preprocess(rng):
     pts = rng.normal(size=(1000, 3)).astype(np.float32)
     centred, off = Pre.center_at_origin(pts)
@@ -177,7 +204,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     for name, fn, seed in [("kabsch", gen_kabsch, 100), ("quat_avg", gen_quat_avg, 101), ("add", gen_add, 102),
                            ("fps", gen_fps, 103), ("ball_query", gen_ball_query, 104),
-                           ("preprocess", gen_preprocess, 105)]:
+                           ("preprocess", gen_preprocess, 105), ("metrics", gen_metrics, 106)]:
         data = fn(np.random.default_rng(seed))
         path = os.path.join(OUT, name + ".npz")
         np.savez_compressed(path, **data)
