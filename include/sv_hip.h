@@ -185,6 +185,20 @@ int sv_add_metric_batched(const double* points, const int32_t* P, int Pmax, cons
                           const double* pred_pose, int B, double* add_out, sv_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * N3  point-to-point ICP refinement (replaces utils/icp.py:13-83 = open3d registration_icp with
+ *      TransformationEstimationPointToPoint; call sites app/inference_engine.py:358-362)
+ *   src float32[S][3] (CAD model points), tgt float32[T][3] (end-effector crop), init_T double[16] row-major 4x4
+ *   source->target (NULL = identity).  Correspondence = nearest target point within max_distance; update = Kabsch on
+ *   the correspondences; stops when |d fitness| < rel_fitness and |d rmse| < rel_rmse between two evaluations or after
+ *   max_iterations updates.  out_T double[16]; out_stats double[3] = {fitness, inlier rmse, updates applied}.
+ *   The whole iteration runs on the stream without host read-backs.
+ * ------------------------------------------------------------------------------------------- */
+size_t sv_icp_workspace_bytes(int64_t S);
+int sv_icp_point2point(const float* src, int64_t S, const float* tgt, int64_t T, const double* init_T,
+                       double max_distance, int max_iterations, double rel_fitness, double rel_rmse, void* workspace,
+                       size_t workspace_bytes, double* out_T, double* out_stats, sv_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * A8  PointNet++ sampling / grouping  (replace model/pointnet2_utils.py:65-86 farthest_point_sample,
  *      :89-109 query_ball_point, utils/data.py:13-34 numpy FPS)
  * ------------------------------------------------------------------------------------------- */

@@ -54,6 +54,9 @@ SIGNATURES = {
     "sv_kabsch_batched": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P]),
     "sv_quat_avg_batched": (c_int, [_P, _P, _P, c_int, c_int, _P, _P]),
     "sv_add_metric_batched": (c_int, [_P, _P, c_int, _P, _P, c_int, _P, _P]),
+    "sv_icp_workspace_bytes": (c_size_t, [c_int64]),
+    "sv_icp_point2point": (c_int, [_P, c_int64, _P, c_int64, _P, c_double, c_int, c_double, c_double, _P, c_size_t, _P, _P,
+                                   _P]),
     "sv_fps": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
     "sv_ball_query": (c_int, [_P, _P, c_int, c_int, c_int, c_double, c_int, _P, _P]),
 }

@@ -6,7 +6,8 @@ the Kabsch / averaging solves run through libsvhip.  Differences that are delibe
   * checkpoints: the reference's paths are not shipped.  `allow_random_init=True` keeps
     `pred_enabled` when a checkpoint is missing so the pipeline can be exercised with seeded random weights;
     with the reference's behaviour (False) a missing checkpoint disables prediction (all-zero segmentation, :281-283).
-  * ICP refinement (utils/icp.py, open3d) is out of scope: `icp_enabled` must stay False.
+  * ICP refinement (utils/icp.py) runs on libsvhip (sv_icp_point2point); the CAD model points are passed in
+    (`cad_points=`) because the reference's mesh asset does not ship with this build.
   * check_sanity: the reference derives ground-truth key points from the EE crop with utils/data.py:141-335
     get_6_key_points (label synthesis, out of scope); here the expected key points are the six constant
     reference_key_points moved by the predicted EE pose — the same quantity the reference compares against.
@@ -52,12 +53,19 @@ def checkpoint_restore(model, f=None, device="cuda"):
 
 
 class InferenceEngine:
-    def __init__(self, calibration_only=False, device="cuda", allow_random_init=False, seed=1):
+    def __init__(self, calibration_only=False, device="cuda", allow_random_init=False, seed=1, cad_points=None):
         self._config = config.Config()
         cfg = self._config
         self.device = torch.device(device)
+        # CAD-to-crop ICP (utils/icp.py): the reference samples its CAD points from app/hand_files/hand_notblender.obj,
+        # which does not ship with this build -> the caller supplies the model points
+        self.match_icp = None
         if cfg.INFERENCE.icp_enabled:
-            raise NotImplementedError("ICP refinement is out of scope of this build: set INFERENCE.icp_enabled=False")
+            if cad_points is None:
+                raise ValueError("INFERENCE.icp_enabled needs cad_points (the CAD model of the end effector, [P,3])")
+            from ..utils.icp import get_point2point_matcher
+
+            self.match_icp = get_point2point_matcher(cad_points, device=self.device)
         self.reference_key_points = REFERENCE_KEY_POINTS.copy()
         self.ee_min_width = abs(self.reference_key_points[0][1] - self.reference_key_points[1][1]) - 0.02
         self.ee_min_height = abs(self.reference_key_points[0][2] - self.reference_key_points[2][2]) - 0.01
@@ -224,6 +232,9 @@ class InferenceEngine:
         result.key_points = list(zip(kp_classes, kp_coords))
         result.key_points_pose = self.predict_pose_from_kp(kp_coords, kp_classes)
         result.is_confident = self.check_sanity(data, result)
+        if self.match_icp is not None:  # app/inference_engine.py:358-362
+            result.ee_pose = self.match_icp(ee_pts, result.ee_pose)
+            result.key_points_pose = self.match_icp(ee_pts, result.key_points_pose)
         if data.ee2base_pose is not None:
             result.base_pose = get_base2cam_pose(result.ee_pose, data.ee2base_pose)
             if result.key_points_pose is not None:

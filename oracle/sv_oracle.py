@@ -529,3 +529,44 @@ def query_ball_point(radius, nsample, xyz, new_xyz):
             row[: min(nsample, len(idx))] = idx[:nsample]
             out[b, s] = row
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# ICP (parity unpinned: open3d is not installable here; restated from Open3D's published registration_icp loop with
+# TransformationEstimationPointToPoint, the call made by utils/icp.py:66-72)
+# ------------------------------------------------------------------------------------------------------------------
+def icp_point2point(src, tgt, init_T=None, max_distance=0.1, max_iterations=30, rel_fitness=1e-6, rel_rmse=1e-6):
+    """Returns (T 4x4, fitness, inlier rmse, updates applied).  Nearest neighbour by brute force in float32 (first
+    minimum), inliers d <= max_distance, update = Kabsch on the inlier pairs, stop when fitness and rmse both move by
+    less than the tolerances between two evaluations."""
+    src = np.asarray(src, dtype=np.float32)
+    tgt = np.asarray(tgt, dtype=np.float32)
+    T = np.eye(4) if init_T is None else np.array(init_T, dtype=np.float64)
+    max_d2 = np.float32(max_distance * max_distance)
+    prev = None
+    updates = 0
+    for it in range(max_iterations + 1):
+        p = (src.astype(np.float64) @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
+        nn = np.empty(len(p), dtype=np.int64)
+        d2 = np.empty(len(p), dtype=np.float32)
+        for s in range(0, len(p), 512):  # blocked brute force
+            d = p[s:s + 512, None, :] - tgt[None, :, :]
+            dd = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+            nn[s:s + 512] = dd.argmin(axis=1)
+            d2[s:s + 512] = dd[np.arange(dd.shape[0]), nn[s:s + 512]]
+        inl = d2 <= max_d2
+        n = int(inl.sum())
+        fitness = n / len(p)
+        rmse = float(np.sqrt(d2[inl].astype(np.float64).sum() / n)) if n else 0.0
+        if prev is not None and abs(prev[0] - fitness) < rel_fitness and abs(prev[1] - rmse) < rel_rmse:
+            break
+        prev = (fitness, rmse)
+        if n < 3 or it == max_iterations:
+            break
+        pt = src[inl].astype(np.float64) @ T[:3, :3].T + T[:3, 3]
+        R, t = get_rigid_transform_3D(pt, tgt[nn[inl]].astype(np.float64))
+        U = np.eye(4)
+        U[:3, :3], U[:3, 3] = R, t
+        T = U @ T
+        updates += 1
+    return T, fitness, rmse, updates

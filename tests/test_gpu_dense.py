@@ -91,3 +91,48 @@ def test_ball_query_vs_reference_golden(gpu, golden):
     # point sits within float32 rounding of the sphere surface
     same = (got == g["idx"]).all(axis=2)
     assert same.mean() > 0.99, f"only {same.mean():.4f} of the query rows identical"
+
+
+def _ee_model(n, seed):
+    """Points on the surface of a 0.10 x 0.22 x 0.13 m box with an asymmetric ridge (a stand-in CAD model)."""
+    rng = np.random.default_rng(seed)
+    p = rng.uniform(-0.5, 0.5, size=(n, 3))
+    ax = rng.integers(0, 3, size=n)
+    p[np.arange(n), ax] = np.where(rng.random(n) < 0.5, -0.5, 0.5)
+    p *= np.array([0.10, 0.22, 0.13])
+    ridge = (p[:, 1] > 0.05) & (p[:, 2] > 0.06)
+    p[ridge, 0] += 0.03
+    return p.astype(np.float32)
+
+
+def test_icp_matches_oracle_and_recovers_pose(gpu, oracle):
+    from mrcc_amd.utils import icp as I
+    from mrcc_amd.utils.transformation import get_quaternion_rotation_matrix
+
+    rng = np.random.default_rng(1)
+    cad = _ee_model(3000, 0)
+    q = np.array([0.9, 0.2, -0.3, 0.1])
+    q /= np.linalg.norm(q)
+    R = get_quaternion_rotation_matrix(q, switch_w=False)
+    t = np.array([0.3, -0.1, 0.9])
+    crop = (_ee_model(2500, 5).astype(np.float64) @ R.T + t + rng.normal(0, 5e-4, size=(2500, 3))).astype(np.float32)
+    # initial guess: 6 degrees / 1.5 cm off
+    dq = np.array([1.0, 0.03, -0.04, 0.02])
+    dq /= np.linalg.norm(dq)
+    T0 = np.eye(4)
+    T0[:3, :3] = get_quaternion_rotation_matrix(dq, switch_w=False) @ R
+    T0[:3, 3] = t + np.array([0.015, -0.01, 0.005])
+    T, fit, rmse, iters = I.icp_point2point(cad, crop, T0, device=gpu)
+    To, fo, ro, io = oracle.icp_point2point(cad, crop, T0)
+    assert iters == io and abs(fit - fo) < 1e-9 and abs(rmse - ro) < 1e-7
+    assert np.abs(T - To).max() < 1e-7
+    assert np.abs(T[:3, 3] - t).max() < 3e-3 and np.abs(T[:3, :3] - R).max() < 2e-2 and fit > 0.99
+    assert abs(np.linalg.det(T[:3, :3]) - 1) < 1e-12
+    # max_iterations = 0 only evaluates; the reference-shaped matcher returns a pose
+    T1, f1, r1, it1 = I.icp_point2point(cad, crop, T0, max_iterations=0, device=gpu)
+    assert it1 == 0 and np.array_equal(T1, T0) and r1 > rmse
+    match = I.get_point2point_matcher(cad, device=gpu)
+    pose0 = np.concatenate([T0[:3, 3], [1.0, 0, 0, 0]])
+    assert match(None, pose0) is pose0
+    pose = match(crop, np.concatenate([T0[:3, 3], oracle.get_q_from_matrix(T0[:3, :3])]))
+    assert np.abs(pose[:3] - t).max() < 3e-3
