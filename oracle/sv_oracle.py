@@ -9,6 +9,8 @@ PARITY STATUS
     third-party dependency (requirements.txt:101), is not installable here and the reference holds no golden
     vectors for it (SURVEY.md §8c).  The semantics restated are ME's public API semantics (SURVEY.md Appendix B);
     self-consistency is checked against dense torch conv3d / BatchNorm1d / Linear in tests/.
+  * ICP (icp_point2point): **parity unpinned** — open3d (utils/icp.py:5) is not installable here; restated from
+    Open3D's published registration_icp loop.
   * dense solves, metrics, FPS, ball query: pinned by tests/golden/*.npz generated from the reference's own
     utils/transformation.py, utils/calibration.py, utils/metrics.py, utils/data.py, model/pointnet2_utils.py
     (tools/make_golden.py).
