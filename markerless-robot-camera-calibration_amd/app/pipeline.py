@@ -35,11 +35,17 @@ def build_unet_plans(cm, levels=4):
 
 
 class FramePipeline:
-    def __init__(self, device, levels=4, encoder_only=False):
+    def __init__(self, device, levels=4, encoder_only=False, compute_streams=1):
         self.device = torch.device(device)
         self.levels = levels
         self.encoder_only = encoder_only
         self.prep_stream = torch.cuda.Stream(device=self.device)
+        # compute_streams > 1: consecutive frames run on alternating streams, so the small-pyramid-level and thin-layer
+        # kernels of one frame (which cannot fill 256 CUs) overlap the big convolutions of its neighbour
+        self.compute_streams = [torch.cuda.Stream(device=self.device) for _ in range(compute_streams)] \
+            if compute_streams > 1 else []
+        self._next_stream = 0
+        self.single = False  # True: run every frame on the first compute stream (isolated kernel timing)
         self._retired = collections.deque()
 
     def prepare(self, coords4, feats, tag=None):
@@ -63,10 +69,16 @@ class FramePipeline:
         return PreparedFrame(field, x, ready, tag)
 
     def run(self, prepared, fn):
-        """Run fn(x, field) on the current (compute) stream once the frame is ready; returns fn's result."""
-        compute = torch.cuda.current_stream(self.device)
+        """Run fn(x, field) on a compute stream once the frame is ready; returns fn's result (valid on that stream;
+        `drain()` or an event wait orders it against other streams)."""
+        if self.compute_streams:
+            compute = self.compute_streams[0 if self.single else self._next_stream]
+            self._next_stream = (self._next_stream + 1) % len(self.compute_streams)
+        else:
+            compute = torch.cuda.current_stream(self.device)
         compute.wait_event(prepared.ready)
-        out = fn(prepared.x, prepared.field)
+        with torch.cuda.stream(compute):
+            out = fn(prepared.x, prepared.field)
         prepared.done = torch.cuda.Event()
         prepared.done.record(compute)
         self._retired.append(prepared)
@@ -75,5 +87,7 @@ class FramePipeline:
         return out
 
     def drain(self):
+        for st in self.compute_streams:
+            st.synchronize()
         torch.cuda.current_stream(self.device).synchronize()
         self._retired.clear()
