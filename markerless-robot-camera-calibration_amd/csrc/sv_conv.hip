@@ -421,8 +421,9 @@ static int select_and_launch(const ConvParams& p, hipStream_t stream) {
     Candidate c = {0, 0, 0, 0};
     if (sscanf(f, "%d,%d,%d", &c.tm, &c.wn, &c.nt) == 3 && c.nt == list[0].nt) return launch_candidate(c, p, stream);
   }
+  static const double want_scale = getenv("SV_CONV_WANT_SCALE") ? atof(getenv("SV_CONV_WANT_SCALE")) : 1.0;
   for (int i = 0; i < n; ++i)
-    if (candidate_wgs(list[i], p) >= list[i].want) return launch_candidate(list[i], p, stream);
+    if ((double)candidate_wgs(list[i], p) >= want_scale * (double)list[i].want) return launch_candidate(list[i], p, stream);
   return launch_candidate(list[n - 1], p, stream);
 }
 
