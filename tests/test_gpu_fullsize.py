@@ -119,3 +119,55 @@ def test_alive_unet_and_vote_head(gpu):
         pf = v.slice(f).F
         centre = get_pred_center(pf, pts)
         assert centre.shape == (3,) and np.isfinite(centre).all()
+
+
+def test_cfg3_batch64_seg_vote_and_pose(gpu, oracle):
+    """BASELINE configs[2]: 64 frames in one sparse tensor (batch column), segmentation + vote heads, then 64 Kabsch
+    problems in one launch.  Checks: batched == per-frame (bit-exact, spot-checked), per-frame vote centres, and the
+    batched pose solve against the oracle's SVD restatement and the generating poses."""
+    import mrcc_amd
+    from mrcc_amd import MinkowskiEngine as ME
+    from mrcc_amd.model.backbone.minkunet import MinkUNet14A
+    from mrcc_amd.model.robotnet_segmentation import _classification_head
+    from mrcc_amd.utils import transformation as T
+
+    B = 64
+    torch.manual_seed(0)
+    Head = _classification_head(MinkUNet14A, lambda: 3, "SegSmall")
+    Vote = _classification_head(MinkUNet14A, lambda: 2, "VoteSmall")
+    seg = Head(3, num_classes=3).to(gpu).eval()
+    vote = Vote(3, num_classes=2).to(gpu).eval()
+    crops = [mrcc_amd.synth.gen_ee_crop(s, n=1500) for s in range(B)]
+    with torch.no_grad():
+        coords = ME.utils.batched_coordinates([torch.from_numpy(c[0] * np.float32(100)) for c in crops],
+                                              dtype=torch.float32)
+        feats = torch.from_numpy(np.concatenate([c[1] for c in crops]))
+        field = ME.TensorField(feats, coords, device=gpu)
+        x = field.sparse()
+        assert int(x.C[:, 0].max()) == B - 1
+        s_out = seg(x)
+        v_out = vote(x).slice(field).F
+        labels, _ = s_out.slice_argmax(field)
+        assert labels.shape[0] == B * 1500
+        # spot-check three frames against single-frame runs
+        for b in (0, 31, 63):
+            c1 = torch.from_numpy(np.concatenate([np.zeros((1500, 1), np.float32), crops[b][0] * np.float32(100)], 1))
+            f1 = ME.TensorField(torch.from_numpy(crops[b][1]), c1, device=gpu)
+            l1, _ = seg(f1.sparse()).slice_argmax(f1)
+            assert torch.equal(labels[b * 1500:(b + 1) * 1500], l1)
+    # vote centres per frame (utils/output.py:45-64: mean of the 8 highest-vote points)
+    from mrcc_amd.utils.output import get_pred_center
+
+    for b in (0, 63):
+        centre = get_pred_center(v_out[b * 1500:(b + 1) * 1500], crops[b][0])
+        assert np.isfinite(centre).all() and np.abs(centre - crops[b][2][:3]).max() < 0.25  # inside the crop
+    # 64 Kabsch problems in one launch
+    ref = np.repeat(mrcc_amd.synth.REFERENCE_KEY_POINTS[None], B, axis=0)
+    tgt = np.stack([c[3] for c in crops])
+    R, t, q = T.get_rigid_transform_3D_batched(ref, tgt, device=gpu)
+    for b in range(B):
+        Ro, to = oracle.get_rigid_transform_3D(ref[b], tgt[b])
+        assert np.abs(R[b] - Ro).max() < 1e-9 and np.abs(t[b] - to).max() < 1e-9
+        pose = crops[b][2]
+        assert np.abs(t[b] - pose[:3]).max() < 5e-3  # 1 mm key-point noise
+        assert min(np.abs(q[b] - pose[3:]).max(), np.abs(q[b] + pose[3:]).max()) < 5e-2
