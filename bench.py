@@ -221,6 +221,16 @@ def main():
                 "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
                 "compute_streams": args.streams,
             }
+            # HBM traffic of this kernel from PMC counters (separate rocprofv3 --pmc passes over this command, calibrated
+            # on a known-traffic launch as the MI355X guide prescribes): profiles/r01_traffic.json, GB per launch
+            try:
+                tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"].get(name)
+                if tr:
+                    roofline["traffic"] = tr["traffic_GB_per_launch"]
+                    roofline["traffic_unit"] = "GB per launch (PMC, calibrated; profiles/r01_traffic.json)"
+                    roofline["algorithmic_GB_per_launch"] = round(warm[name]["bytes"] / warm[name]["launches"] / 1e9, 4)
+            except (OSError, KeyError, ValueError):
+                pass
             iso = warm[name]
             iso_tf = iso["flops"] / (iso["ms"] * 1e-3) / 1e12
             # the same instance with nothing else on the GPU (warm-up pass on one compute stream): with several compute
