@@ -323,6 +323,14 @@ __global__ __launch_bounds__(256) void iota_key_kernel(const uint32_t* __restric
     for (int k = 0; k < 27; ++k) k2 |= ((m >> k) & 1u) << kb.pos[k];
     m = k2;
   }
+  // Sort by the rank of the mask in reflected-Gray order rather than by its binary value: neighbours in the sorted order
+  // then differ in fewer offsets, so a 16-row sub-tile's union of offsets is smaller (slot efficiency 0.854 -> 0.872 on
+  // the 2 cm room level; tools/tile_experiment.py).
+  m ^= m >> 1;
+  m ^= m >> 2;
+  m ^= m >> 4;
+  m ^= m >> 8;
+  m ^= m >> 16;
   key[i] = m;
 }
 

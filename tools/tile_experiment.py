@@ -54,9 +54,21 @@ def level_stats(c, ts, name):
     for rank, k in enumerate(bitorder):
         m2 |= act[k].astype(np.int64) << (26 - rank)
     bym2 = np.argsort(m2, kind="stable")
+    # the plan's key: corners, edges, faces, centre as MSBs (rarest first), ranked in reflected-Gray order
+    def cls(k):
+        return abs(k % 3 - 1) + abs((k // 3) % 3 - 1) + abs(k // 9 - 1)
+    m3 = np.zeros(V, dtype=np.int64)
+    for rank, k in enumerate(sorted(range(27), key=lambda k: (-cls(k), k))):
+        m3 |= act[k].astype(np.int64) << (26 - rank)
+    byrare = np.argsort(m3, kind="stable")
+    g3 = m3.copy()
+    for s_ in (1, 2, 4, 8, 16):
+        g3 ^= g3 >> s_
+    bygray = np.argsort(g3, kind="stable")
     # popcount-then-mask
     for g in (16, 32, 64, 128):
-        print(f"   g={g:4d}: morton {eff(ident,g):.3f}  mask-sort {eff(bymask,g):.3f}  entropy-bit-sort {eff(bym2,g):.3f}")
+        print(f"   g={g:4d}: morton {eff(ident,g):.3f}  mask-sort {eff(bymask,g):.3f}  entropy-bit-sort {eff(bym2,g):.3f}"
+              f"  rare-first {eff(byrare,g):.3f}  rare-first+gray (plan) {eff(bygray,g):.3f}")
     return c
 
 n, L, scale = 200000, 2.4, 50
