@@ -404,22 +404,27 @@ static int64_t candidate_wgs(const Candidate& c, const ConvParams& p) {
 }
 
 static int select_and_launch(const ConvParams& p, hipStream_t stream) {
+  // The last entry of a list serves the small pyramid levels, where a layer is a few hundred short workgroups and its
+  // duration is the serial (offset, chunk) chain of one of them: 16-row tiles with 128-channel chunks are fastest
+  // there (tools/sweep_small.sh, profiles/r01_conv_small_level_sweep.txt).
   static const Candidate wide3[] = {{64, 4, 3, 2500}, {32, 4, 3, 1500}, {32, 2, 3, 0}};
+  static const Candidate wide3_128[] = {{64, 4, 3, 2500}, {32, 4, 3, 1500}, {16, 4, 2, 0}};  // Cout % 128 == 0
   static const Candidate wide2[] = {{128, 4, 2, 1300}, {64, 4, 2, 1500}, {32, 4, 2, 1500}, {32, 2, 2, 0}};
+  static const Candidate wide2_64[] = {{128, 4, 2, 1300}, {64, 4, 2, 1500}, {32, 4, 2, 1500}, {16, 4, 1, 0}};  // % 64
   static const Candidate c64[] = {{64, 4, 1, 1500}, {32, 4, 1, 1500}, {16, 4, 1, 0}};
   static const Candidate c32[] = {{128, 2, 1, 1500}, {64, 2, 1, 1500}, {32, 2, 1, 0}};
   static const Candidate c16[] = {{128, 1, 1, 1500}, {64, 1, 1, 0}};
   const Candidate* list;
   int n;
   const int Cout = p.Cout;
-  if (Cout > 128 && (Cout % 192 == 0 || Cout % 96 == 0 || Cout > 2048)) { list = wide3; n = 3; }
-  else if (Cout > 64) { list = wide2; n = 4; }
+  if (Cout > 128 && (Cout % 192 == 0 || Cout % 96 == 0 || Cout > 2048)) { list = Cout % 128 == 0 ? wide3_128 : wide3; n = 3; }
+  else if (Cout > 64) { list = Cout % 64 == 0 ? wide2_64 : wide2; n = 4; }
   else if (Cout > 32) { list = c64; n = 3; }
   else if (Cout > 16) { list = c32; n = 3; }
   else { list = c16; n = 2; }
   if (const char* f = getenv("SV_CONV_FORCE")) {  // "tm,wn,nt": experiments only
     Candidate c = {0, 0, 0, 0};
-    if (sscanf(f, "%d,%d,%d", &c.tm, &c.wn, &c.nt) == 3 && c.nt == list[0].nt) return launch_candidate(c, p, stream);
+    if (sscanf(f, "%d,%d,%d", &c.tm, &c.wn, &c.nt) == 3) return launch_candidate(c, p, stream);
   }
   static const double want_scale = getenv("SV_CONV_WANT_SCALE") ? atof(getenv("SV_CONV_WANT_SCALE")) : 1.0;
   for (int i = 0; i < n; ++i)

@@ -11,7 +11,9 @@ TIMER = None  # set by bench.py
 
 _CANDIDATES = {
     "wide3": [(64, 4, 3, 2500), (32, 4, 3, 1500), (32, 2, 3, 0)],
+    "wide3_128": [(64, 4, 3, 2500), (32, 4, 3, 1500), (16, 4, 2, 0)],
     "wide2": [(128, 4, 2, 1300), (64, 4, 2, 1500), (32, 4, 2, 1500), (32, 2, 2, 0)],
+    "wide2_64": [(128, 4, 2, 1300), (64, 4, 2, 1500), (32, 4, 2, 1500), (16, 4, 1, 0)],
     "c64": [(64, 4, 1, 1500), (32, 4, 1, 1500), (16, 4, 1, 0)],
     "c32": [(128, 2, 1, 1500), (64, 2, 1, 1500), (32, 2, 1, 0)],
     "c16": [(128, 1, 1, 1500), (64, 1, 1, 0)],
@@ -22,9 +24,9 @@ def conv_kernel_config(Cout, Vpad):
     """Mirror of select_and_launch() in csrc/sv_conv.hip -> template instance name as rocprofv3 prints it:
     conv_fwd_kernel<TM, WAVES_N, NT>."""
     if Cout > 128 and (Cout % 192 == 0 or Cout % 96 == 0 or Cout > 2048):
-        cands = _CANDIDATES["wide3"]
+        cands = _CANDIDATES["wide3_128" if Cout % 128 == 0 else "wide3"]
     elif Cout > 64:
-        cands = _CANDIDATES["wide2"]
+        cands = _CANDIDATES["wide2_64" if Cout % 64 == 0 else "wide2"]
     elif Cout > 32:
         cands = _CANDIDATES["c64"]
     elif Cout > 16:

@@ -69,7 +69,9 @@ def test_kernel_dispatch_mirror():
 
     assert c(384, 88192) == "conv_fwd_kernel<64, 4, 3>"
     assert c(384, 26624) == "conv_fwd_kernel<32, 4, 3>"
-    assert c(384, 1792) == "conv_fwd_kernel<32, 2, 3>"
+    assert c(384, 1792) == "conv_fwd_kernel<16, 4, 2>"
+    assert c(192, 1792) == "conv_fwd_kernel<32, 2, 3>"
+    assert c(256, 512) == "conv_fwd_kernel<16, 4, 1>"
     assert c(32, 26624) == "conv_fwd_kernel<32, 2, 1>"
     assert c(1024, 88192) == "conv_fwd_kernel<128, 4, 2>"
 
