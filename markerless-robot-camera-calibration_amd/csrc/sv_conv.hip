@@ -15,6 +15,7 @@
 // A missing neighbour contributes fma(0, w, acc) = acc.
 #include <stdio.h>
 #include <stdlib.h>
+#include <vector>
 
 #include "sv_common.h"
 
@@ -47,6 +48,7 @@ struct ConvParams {
   int vec_b;  // Cout % 4 == 0 && W aligned -> float4 weight loads
   int ntiles;
   int ny;
+  unsigned long long* trace;  // SV_CONV_TRACE experiments: per-workgroup {start, end, hw id, steps}; null otherwise
 };
 
 constexpr int PLAN_TILE = SV_TILE_ROWS;  // plans (perm / nbr_s / submask) are laid out in 128-row tiles
@@ -98,6 +100,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+  unsigned long long trace_t0 = 0;
+  int trace_steps = 0;
+  if (p.trace) trace_t0 = wall_clock64();
   // 1-D grid, longest tiles first (list scheduling): plan tiles are visited in the plan's tile_order (sorted by active
   // (offset, sub-tile) slots, descending); without one, in reverse plan order (rows are sorted by neighbour key, so
   // the tiles with the most neighbour offsets sit at the end).
@@ -137,24 +142,26 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
     idx_s[e] = n;
   }
 
-  // ---- step iterator over (active offset, chunk); the plan's submask words cover 128 rows = 8 sub-tiles
+  // ---- step iterator over (active offset, chunk).  The plan's submask words cover 128 rows = 8 sub-tiles; lane k of
+  //      every wave keeps the tile's word for offset k in a register and a ballot gives the active-offset set, so
+  //      stepping to the next active offset is a bit scan + v_readlane (no memory access between steps).
   const int64_t sm_word = row0 / PLAN_TILE;
   const int sm_shift = (int)((row0 % PLAN_TILE) / 16);
-  auto submask_of = [&](int k) -> uint32_t {
-    return p.submask ? ((p.submask[sm_word * K + k] >> sm_shift) & ((1u << SUBS) - 1u)) : dense_mask;
-  };
-  int k_n = 0;
-  uint32_t sm_n = 0;
-  while (k_n < K && (sm_n = submask_of(k_n)) == 0) ++k_n;
+  uint32_t my_sm = 0;
+  if (lane < K) my_sm = p.submask ? ((p.submask[sm_word * K + lane] >> sm_shift) & ((1u << SUBS) - 1u)) : dense_mask;
+  const uint32_t amask = (uint32_t)__ballot(my_sm != 0);
+  int k_n = amask ? __builtin_ctz(amask) : K;
+  uint32_t sm_n = amask ? (uint32_t)__builtin_amdgcn_readlane((int)my_sm, k_n) : 0u;
   int c_n = 0;
-  bool have_n = k_n < K;
+  bool have_n = amask != 0;
   auto advance = [&]() {
     c_n += KC;
     if (c_n >= Cin) {
       c_n = 0;
-      ++k_n;
-      while (k_n < K && (sm_n = submask_of(k_n)) == 0) ++k_n;
-      have_n = k_n < K;
+      const uint32_t rest = amask & ~((2u << k_n) - 1u);
+      have_n = rest != 0;
+      k_n = have_n ? __builtin_ctz(rest) : K;
+      sm_n = (uint32_t)__builtin_amdgcn_readlane((int)my_sm, have_n ? k_n : 0);
     }
   };
 
@@ -281,6 +288,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
         }
         if (FAST || have_n) load_b(wnext, kb, c_n, ksteps_next, ks, b[ks]);
       }
+      ++trace_steps;
       if (!have_n) break;
       // ---- hand over to the next step
       store_a(As + (buf ^ 1) * (TM_ * SA), sm_n);
@@ -340,6 +348,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
       }
     }
   }
+  if (p.trace && tid == 0) {  // 100 MHz wall clock; HW_REG_HW_ID (CU / SE) and HW_REG_XCC_ID place the workgroup
+    unsigned long long* t = p.trace + (size_t)blockIdx.x * 4;
+    t[0] = trace_t0;
+    t[1] = wall_clock64();
+    t[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+           (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+    t[3] = (unsigned)trace_steps;
+  }
 }
 
 template <int TM_, int WAVES_N, int NT>
@@ -350,11 +366,28 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
   q.ny = (p.Cout + Cfg::TN - 1) / Cfg::TN;
   dim3 grid((unsigned)(q.ntiles * q.ny));
   const bool fast = p.vec_a && (p.Cout % Cfg::TN == 0);
+  // SV_CONV_TRACE=<file> (experiments only): trace the launch per workgroup, synchronise, append to <file>
+  // (tools/wg_trace.py reads it: residency over time, per-CU tail, time per step)
+  static const char* trace_path = getenv("SV_CONV_TRACE");
+  q.trace = nullptr;
+  if (trace_path) SV_HIP(hipMalloc((void**)&q.trace, (size_t)grid.x * 4 * sizeof(unsigned long long)));
   if (fast)
     hipLaunchKernelGGL((conv_fwd_kernel<TM_, WAVES_N, NT, true>), grid, dim3(256), Cfg::lds_bytes(p.K), stream, q);
   else
     hipLaunchKernelGGL((conv_fwd_kernel<TM_, WAVES_N, NT, false>), grid, dim3(256), Cfg::lds_bytes(p.K), stream, q);
   SV_LAUNCH_CHECK();
+  if (q.trace) {
+    std::vector<unsigned long long> host((size_t)grid.x * 4);
+    SV_HIP(hipStreamSynchronize(stream));
+    SV_HIP(hipMemcpy(host.data(), q.trace, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    SV_HIP(hipFree(q.trace));
+    if (FILE* f = fopen(trace_path, "ab")) {
+      const long long hdr[8] = {0x5356545243ll, (long long)grid.x, TM_, WAVES_N, NT, q.ny, p.K, p.Cin};
+      fwrite(hdr, sizeof(hdr), 1, f);
+      fwrite(host.data(), sizeof(unsigned long long), host.size(), f);
+      fclose(f);
+    }
+  }
   return SV_OK;
 }
 
@@ -460,5 +493,6 @@ extern "C" int sv_conv_fwd(const float* in, int64_t in_ld, int Cin, const float*
   p.vec_b = (Cout % 4 == 0) && (((uintptr_t)W & 15) == 0);
   p.ntiles = 0;
   p.ny = 0;
+  p.trace = nullptr;
   return select_and_launch(p, stream);
 }

@@ -18,7 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--cin", type=int, default=384)
 ap.add_argument("--cout", type=int, default=384)
 ap.add_argument("--level", type=int, default=0)
-ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--iters", type=int, default=200)  # long enough for the clocks to settle
 ap.add_argument("--points", type=int, default=200000)
 ap.add_argument("--kind", default="k3")
 ap.add_argument("--cube", type=int, default=0, help="solid cube of this edge length (voxels) instead of the room cloud")
