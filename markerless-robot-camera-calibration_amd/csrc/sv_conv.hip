@@ -66,13 +66,26 @@ constexpr int chunk_for(int tm, int waves_n) {
 //   operands for its NT tiles are NT consecutive floats of a weight row (one dwordxNT load straight from L2/HBM into
 //   registers — the weight slab is not shared between waves, an LDS round trip would be pure overhead) and the
 //   epilogue stores NT consecutive floats per lane.
-template <int TM_, int WAVES_N, int NT>
+// Thin layers (Cin = 3 / 16 / 32 / 64) FUSE several kernel offsets into one pipeline step (CPO = channels per offset,
+// compile-time, = Cin): the A tile row of a step is the concatenation of GK neighbours' Cin channels, which is a
+// contiguous run of GK * Cin rows of W[K][Cin][Cout] - the same ascending (k, c) accumulation chain in 27 * Cin / 128
+// steps instead of 27.  CPO = 0 is the one-offset-per-step form used by the wide layers.
+constexpr int fused_offsets(int cpo) { return cpo == 0 ? 1 : (cpo < 8 ? 27 : (128 / cpo > 0 ? 128 / cpo : 1)); }
+constexpr int lds_row_stride(int kc) {
+  // smallest stride >= kc + 2 for which the 16x16x4 operand read (lane = row li, k-offset lq: word li * SA + lq)
+  // touches 64 distinct LDS banks: SA mod 64 = 34, or SA = 4 * odd
+  for (int sa = kc + 2;; ++sa)
+    if (sa % 64 == 34 || (sa % 4 == 0 && (sa / 4) % 2 == 1)) return sa;
+}
+
+template <int TM_, int WAVES_N, int NT, int CPO = 0>
 struct ConvCfg {
   static constexpr int WAVES_M = 4 / WAVES_N;
   static constexpr int MR = TM_ / WAVES_M / 16;  // 16-row sub-tiles per wave
   static constexpr int TN = WAVES_N * NT * 16;   // output channels per workgroup
-  static constexpr int KC = chunk_for(TM_, WAVES_N);
-  static constexpr int SA = KC + 2;              // A row stride in floats: conflict-free 16x16x4 operand reads
+  static constexpr int GK = fused_offsets(CPO);  // kernel offsets per pipeline step
+  static constexpr int KC = CPO ? (GK * CPO + 3) / 4 * 4 : chunk_for(TM_, WAVES_N);  // A columns per step
+  static constexpr int SA = lds_row_stride(KC);  // A row stride in floats
   static constexpr int F4_PER_ROW = KC / 4;      // float4 per gathered row and step
   static constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
   static constexpr int A_F4 = (TM_ + ROWS_PER_PASS - 1) / ROWS_PER_PASS;  // float4 gathers per thread and step
@@ -86,10 +99,10 @@ struct ConvCfg {
 // FAST: float4 gathers, Cout a multiple of TN -> every load is unconditional (out-of-range lanes read a safe address and
 // are zeroed afterwards), so the loop body is straight-line and hipcc can emit COUNTED vmcnt waits; the generic
 // variant keeps per-lane guards (odd channel counts such as Cin = 3 or Cout = 3).
-template <int TM_, int WAVES_N, int NT, bool FAST>
+template <int TM_, int WAVES_N, int NT, bool FAST, int CPO = 0>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
-  using Cfg = ConvCfg<TM_, WAVES_N, NT>;
-  constexpr int MR = Cfg::MR, TN = Cfg::TN, A_F4 = Cfg::A_F4, KC = Cfg::KC, SA = Cfg::SA;
+  using Cfg = ConvCfg<TM_, WAVES_N, NT, CPO>;
+  constexpr int MR = Cfg::MR, TN = Cfg::TN, A_F4 = Cfg::A_F4, KC = Cfg::KC, SA = Cfg::SA, GK = Cfg::GK;
   constexpr int ROWS_PER_PASS = Cfg::ROWS_PER_PASS;
   constexpr int SUBS = TM_ / 16;  // sub-tiles per tile
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -150,11 +163,32 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
   uint32_t my_sm = 0;
   if (lane < K) my_sm = p.submask ? ((p.submask[sm_word * K + lane] >> sm_shift) & ((1u << SUBS) - 1u)) : dense_mask;
   const uint32_t amask = (uint32_t)__ballot(my_sm != 0);
-  int k_n = amask ? __builtin_ctz(amask) : K;
-  uint32_t sm_n = amask ? (uint32_t)__builtin_amdgcn_readlane((int)my_sm, k_n) : 0u;
-  int c_n = 0;
-  bool have_n = amask != 0;
+  // fused-offset steps: a step starts at offset k0 = multiple of GK, its sub-tile mask is the union over its offsets
+  auto fused_mask = [&](int k0) -> uint32_t {
+    uint32_t m = 0;
+#pragma unroll
+    for (int g = 0; g < GK; ++g) m |= (uint32_t)__builtin_amdgcn_readlane((int)my_sm, min(k0 + g, 31));
+    return m;  // lanes >= K hold 0
+  };
+  int k_n, c_n = 0;
+  uint32_t sm_n = 0;
+  bool have_n;
+  if (CPO) {
+    k_n = 0;
+    while (k_n < K && (sm_n = fused_mask(k_n)) == 0) k_n += GK;
+    have_n = k_n < K;
+  } else {
+    k_n = amask ? __builtin_ctz(amask) : K;
+    sm_n = amask ? (uint32_t)__builtin_amdgcn_readlane((int)my_sm, k_n) : 0u;
+    have_n = amask != 0;
+  }
   auto advance = [&]() {
+    if (CPO) {
+      k_n += GK;
+      while (k_n < K && (sm_n = fused_mask(k_n)) == 0) k_n += GK;
+      have_n = k_n < K;
+      return;
+    }
     c_n += KC;
     if (c_n >= Cin) {
       c_n = 0;
@@ -175,12 +209,27 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
       const int r = a_r + ROWS_PER_PASS * j;
       if (FAST) {
         const int rr = (A_F4 * ROWS_PER_PASS > TM_) ? min(r, TM_ - 1) : r;
-        const int n = idx_s[k * TM_ + rr];
-        const int c = c0 + a_cc;
-        const bool ok = (r < TM_) && ((sm >> (rr >> 4)) & 1u) && (n >= 0) && (c < Cin);
+        // fused offsets: column a_cc of the step belongs to offset k + a_cc / CPO, channel a_cc % CPO
+        const int kk = CPO ? k + a_cc / (CPO ? CPO : 1) : k;
+        const int c = CPO ? a_cc % (CPO ? CPO : 1) : c0 + a_cc;
+        const int n = idx_s[min(kk, K - 1) * TM_ + rr];
+        const bool ok = (r < TM_) && ((sm >> (rr >> 4)) & 1u) && (n >= 0) && (CPO ? kk < K : c < Cin);
         const float* src = p.in + (ok ? ((int64_t)n * p.in_ld + c) : 0);
         float4 v = *(const float4*)src;
         ra[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else if (CPO) {
+        float e[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < TM_ && ((sm >> (r >> 4)) & 1u)) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int i = a_cc + q, kk = k + i / (CPO ? CPO : 1), c = i % (CPO ? CPO : 1);
+            if (i < GK * CPO && kk < K) {
+              const int n = idx_s[kk * TM_ + r];
+              if (n >= 0) e[q] = p.in[(int64_t)n * p.in_ld + c];
+            }
+          }
+        }
+        ra[j] = make_float4(e[0], e[1], e[2], e[3]);
       } else {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < TM_ && ((sm >> (r >> 4)) & 1u)) {
@@ -220,19 +269,23 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
   // per k-step only a scalar add remains.  K-steps past the channel tail re-read row 0 of the step (never multiplied).
   const int b_off = lq * Cout + col0;
   auto step_weights = [&](int k, int c0) -> const float* { return p.W + ((int64_t)k * Cin + c0) * Cout; };
+  // valid A columns of the step starting at (k, c0): the rest of the chunk is zero padding
+  auto cols_of = [&](int k, int c0) { return CPO ? min(GK, K - k) * CPO : min(KC, Cin - c0); };
+  auto ksteps_of = [&](int k, int c0) { return (cols_of(k, c0) + 3) >> 2; };
   auto load_b = [&](const float* wstep, int k, int c0, int ksteps_valid, int ks, float (&dst)[NT]) {
     if (FAST) {
       const float* src = wstep + (int64_t)(ks < ksteps_valid ? 4 * ks : 0) * Cout;
 #pragma unroll
       for (int n = 0; n < NT; ++n) dst[n] = src[b_off + n];
     } else {
-      const int c = c0 + 4 * ks + lq;
-      const float* src = p.W + ((int64_t)k * Cin + c) * Cout + col0;
+      // W row of A column i of the step: (k * Cin + c0 + i) - fused offsets are consecutive row blocks of W
+      const int i = 4 * ks + lq;
+      const float* src = p.W + ((int64_t)k * Cin + c0 + i) * Cout + col0;
+      const bool row_ok = i < cols_of(k, c0);
 #pragma unroll
-      for (int n = 0; n < NT; ++n) dst[n] = (c < Cin && col0 + n < Cout) ? src[n] : 0.0f;
+      for (int n = 0; n < NT; ++n) dst[n] = (row_ok && col0 + n < Cout) ? src[n] : 0.0f;
     }
   };
-  auto ksteps_of = [&](int c0) { return (min(KC, Cin - c0) + 3) >> 2; };
 
   __syncthreads();  // idx_s visible
   if (have_n) {
@@ -241,7 +294,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
     uint32_t sm_c = sm_n;
     load_a(k_c, c_c, sm_c);
 #pragma unroll
-    for (int ks = 0; ks < KC / 4; ++ks) load_b(step_weights(k_c, c_c), k_c, c_c, ksteps_of(c_c), ks, b[ks]);
+    for (int ks = 0; ks < KC / 4; ++ks) load_b(step_weights(k_c, c_c), k_c, c_c, ksteps_of(k_c, c_c), ks, b[ks]);
     store_a(As, sm_c);
     advance();
     __syncthreads();
@@ -256,10 +309,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
       //      registers are refilled for the NEXT step as soon as the matrix ops that read them are issued
       const float* a_base = As + buf * (TM_ * SA) + (wm * MR * 16 + li) * SA + lq;
       const uint32_t smw = (sm_c >> (wm * MR)) & ((1u << MR) - 1u);
-      const int ksteps = ksteps_of(c_c);
+      const int ksteps = ksteps_of(k_c, c_c);
       const int kb = have_n ? k_n : 0;
       const float* wnext = step_weights(kb, c_n);
-      const int ksteps_next = ksteps_of(c_n);
+      const int ksteps_next = ksteps_of(kb, c_n);
       float a_cur[MR];
 #pragma unroll
       for (int s = 0; s < MR; ++s) a_cur[s] = a_base[s * 16 * SA];
@@ -358,9 +411,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
   }
 }
 
-template <int TM_, int WAVES_N, int NT>
+template <int TM_, int WAVES_N, int NT, int CPO = 0>
 static int launch_conv(const ConvParams& p, hipStream_t stream) {
-  using Cfg = ConvCfg<TM_, WAVES_N, NT>;
+  using Cfg = ConvCfg<TM_, WAVES_N, NT, CPO>;
   ConvParams q = p;
   q.ntiles = (int)(p.Vpad / TM_);
   q.ny = (p.Cout + Cfg::TN - 1) / Cfg::TN;
@@ -371,10 +424,12 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
   static const char* trace_path = getenv("SV_CONV_TRACE");
   q.trace = nullptr;
   if (trace_path) SV_HIP(hipMalloc((void**)&q.trace, (size_t)grid.x * 4 * sizeof(unsigned long long)));
-  if (fast)
-    hipLaunchKernelGGL((conv_fwd_kernel<TM_, WAVES_N, NT, true>), grid, dim3(256), Cfg::lds_bytes(p.K), stream, q);
+  if (CPO % 4 == 0 ? fast : false)  // odd channel counts (Cin = 3) only exist in the guarded form
+    hipLaunchKernelGGL((conv_fwd_kernel<TM_, WAVES_N, NT, (CPO % 4 == 0), CPO>), grid, dim3(256), Cfg::lds_bytes(p.K),
+                       stream, q);
   else
-    hipLaunchKernelGGL((conv_fwd_kernel<TM_, WAVES_N, NT, false>), grid, dim3(256), Cfg::lds_bytes(p.K), stream, q);
+    hipLaunchKernelGGL((conv_fwd_kernel<TM_, WAVES_N, NT, false, CPO>), grid, dim3(256), Cfg::lds_bytes(p.K), stream,
+                       q);
   SV_LAUNCH_CHECK();
   if (q.trace) {
     std::vector<unsigned long long> host((size_t)grid.x * 4);
@@ -399,12 +454,13 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
 struct Candidate {
   int tm, wn, nt;
   int64_t want;  // chosen when it yields at least this many workgroups (measured on the Cfg-2 pyramid, profiles/)
+  int cpo;       // fused-offset form for this Cin (0 = one offset per step)
 };
 
-template <int TM_, int WAVES_N, int NT>
+template <int TM_, int WAVES_N, int NT, int CPO = 0>
 static bool try_launch(const Candidate& c, const ConvParams& p, hipStream_t stream, int& rc) {
-  if (c.tm == TM_ && c.wn == WAVES_N && c.nt == NT) {
-    rc = launch_conv<TM_, WAVES_N, NT>(p, stream);
+  if (c.tm == TM_ && c.wn == WAVES_N && c.nt == NT && c.cpo == CPO) {
+    rc = launch_conv<TM_, WAVES_N, NT, CPO>(p, stream);
     return true;
   }
   return false;
@@ -425,9 +481,14 @@ static int launch_candidate(const Candidate& c, const ConvParams& p, hipStream_t
       try_launch<64, 4, 1>(c, p, stream, rc) || try_launch<32, 4, 1>(c, p, stream, rc) ||
       try_launch<16, 4, 1>(c, p, stream, rc) || try_launch<128, 2, 1>(c, p, stream, rc) ||
       try_launch<64, 2, 1>(c, p, stream, rc) || try_launch<32, 2, 1>(c, p, stream, rc) ||
-      try_launch<128, 1, 1>(c, p, stream, rc) || try_launch<64, 1, 1>(c, p, stream, rc))
+      try_launch<128, 1, 1>(c, p, stream, rc) || try_launch<64, 1, 1>(c, p, stream, rc) ||
+      // fused-offset forms of the thin layers
+      try_launch<64, 2, 1, 3>(c, p, stream, rc) || try_launch<32, 2, 1, 3>(c, p, stream, rc) ||
+      try_launch<64, 2, 1, 32>(c, p, stream, rc) || try_launch<32, 2, 1, 32>(c, p, stream, rc) ||
+      try_launch<32, 4, 1, 32>(c, p, stream, rc) || try_launch<16, 4, 1, 32>(c, p, stream, rc) ||
+      try_launch<32, 4, 1, 64>(c, p, stream, rc) || try_launch<16, 4, 1, 64>(c, p, stream, rc))
     return rc;
-  set_error("sv_conv_fwd: no kernel instance <%d,%d,%d>", c.tm, c.wn, c.nt);
+  set_error("sv_conv_fwd: no kernel instance <%d,%d,%d> cpo %d", c.tm, c.wn, c.nt, c.cpo);
   return SV_ERR_INVALID;
 }
 
@@ -455,9 +516,21 @@ static int select_and_launch(const ConvParams& p, hipStream_t stream) {
   else if (Cout > 32) { list = c64; n = 3; }
   else if (Cout > 16) { list = c32; n = 3; }
   else { list = c16; n = 2; }
-  if (const char* f = getenv("SV_CONV_FORCE")) {  // "tm,wn,nt": experiments only
-    Candidate c = {0, 0, 0, 0};
-    if (sscanf(f, "%d,%d,%d", &c.tm, &c.wn, &c.nt) == 3) return launch_candidate(c, p, stream);
+  // thin layers: fused-offset forms (the input row is at most 256 B, so one offset per step would be all overhead)
+  static const Candidate f3[] = {{64, 2, 1, 3000, 3}, {32, 2, 1, 0, 3}};
+  static const Candidate f32_32[] = {{64, 2, 1, 3000, 32}, {32, 2, 1, 0, 32}};
+  static const Candidate f32_64[] = {{32, 4, 1, 1500, 32}, {16, 4, 1, 0, 32}};
+  static const Candidate f64_64[] = {{32, 4, 1, 1500, 64}, {16, 4, 1, 0, 64}};
+  static const bool no_fused = getenv("SV_CONV_NO_FUSED") != nullptr;  // experiments only
+  if (p.K > 1 && !no_fused) {
+    if (p.Cin == 3 && Cout > 16 && Cout <= 32) { list = f3; n = 2; }
+    else if (p.Cin == 32 && p.vec_a && Cout == 32) { list = f32_32; n = 2; }
+    else if (p.Cin == 32 && p.vec_a && Cout == 64) { list = f32_64; n = 2; }
+    else if (p.Cin == 64 && p.vec_a && (Cout == 64 || Cout == 128)) { list = f64_64; n = 2; }
+  }
+  if (const char* f = getenv("SV_CONV_FORCE")) {  // "tm,wn,nt[,cpo]": experiments only
+    Candidate c = {0, 0, 0, 0, 0};
+    if (sscanf(f, "%d,%d,%d,%d", &c.tm, &c.wn, &c.nt, &c.cpo) >= 3) return launch_candidate(c, p, stream);
   }
   static const double want_scale = getenv("SV_CONV_WANT_SCALE") ? atof(getenv("SV_CONV_WANT_SCALE")) : 1.0;
   for (int i = 0; i < n; ++i)

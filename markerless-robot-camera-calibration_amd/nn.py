@@ -43,7 +43,7 @@ def conv_forward(feats, weight3, plan, V_out, scale=None, shift=None, residual=N
     timer = profiling.TIMER
     t0 = None
     if timer is not None:
-        kname = profiling.conv_kernel_config(Cout, Vpad)
+        kname = profiling.conv_kernel_config(Cout, Vpad, Cin, K)
         # the first conv of a frame (Cin = 3) follows a cross-stream wait: its event interval absorbs the idle gap
         if Cin >= 8 and timer.want(kname):
             t0 = timer.start()

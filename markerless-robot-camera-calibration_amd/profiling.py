@@ -20,10 +20,26 @@ _CANDIDATES = {
 }
 
 
-def conv_kernel_config(Cout, Vpad):
-    """Mirror of select_and_launch() in csrc/sv_conv.hip -> template instance name as rocprofv3 prints it:
-    conv_fwd_kernel<TM, WAVES_N, NT>."""
-    if Cout > 128 and (Cout % 192 == 0 or Cout % 96 == 0 or Cout > 2048):
+_FUSED = {  # (Cin, Cout) -> candidates of the fused-offset form (thin layers, K > 1)
+    (32, 32): [(64, 2, 1, 3000), (32, 2, 1, 0)],
+    (32, 64): [(32, 4, 1, 1500), (16, 4, 1, 0)],
+    (64, 64): [(32, 4, 1, 1500), (16, 4, 1, 0)],
+    (64, 128): [(32, 4, 1, 1500), (16, 4, 1, 0)],
+}
+
+
+def conv_kernel_config(Cout, Vpad, Cin=None, K=1):
+    """Mirror of select_and_launch() in csrc/sv_conv.hip -> kernel instance name: conv_fwd_kernel<TM, WAVES_N, NT>,
+    with ", fused Cin" appended for the fused-offset form of the thin layers."""
+    fused = None
+    if K > 1 and Cin is not None:
+        if Cin == 3 and 16 < Cout <= 32:
+            fused = [(64, 2, 1, 3000), (32, 2, 1, 0)]
+        else:
+            fused = _FUSED.get((Cin, Cout))
+    if fused is not None:
+        cands = fused
+    elif Cout > 128 and (Cout % 192 == 0 or Cout % 96 == 0 or Cout > 2048):
         cands = _CANDIDATES["wide3_128" if Cout % 128 == 0 else "wide3"]
     elif Cout > 64:
         cands = _CANDIDATES["wide2_64" if Cout % 64 == 0 else "wide2"]
@@ -33,12 +49,13 @@ def conv_kernel_config(Cout, Vpad):
         cands = _CANDIDATES["c32"]
     else:
         cands = _CANDIDATES["c16"]
+    suffix = f", fused {Cin}>" if fused is not None else ">"
     for tm, wn, nt, want in cands:
         tn = wn * nt * 16
         if (Vpad // tm) * ((Cout + tn - 1) // tn) >= want:
-            return f"conv_fwd_kernel<{tm}, {wn}, {nt}>"
+            return f"conv_fwd_kernel<{tm}, {wn}, {nt}{suffix}"
     tm, wn, nt, _ = cands[-1]
-    return f"conv_fwd_kernel<{tm}, {wn}, {nt}>"
+    return f"conv_fwd_kernel<{tm}, {wn}, {nt}{suffix}"
 
 
 class KernelTimer:

@@ -64,5 +64,6 @@ e.record()
 torch.cuda.synchronize()
 ms = s.elapsed_time(e) / args.iters
 fl = 2.0 * P * args.cin * args.cout
+gb = P * (4.0 * args.cin + 8) + 4.0 * V * args.cout + 4.0 * K * args.cin * args.cout  # SURVEY.md 8(d) gather-bytes
 print(f"{args.kind} level{args.level} {args.cin}->{args.cout}: {ms:.3f} ms/launch, {fl / ms / 1e9:.1f} TFLOP/s algorithmic "
-      f"({fl / 1e9:.1f} GFLOP)")
+      f"({fl / 1e9:.1f} GFLOP), gather {gb / ms / 1e6:.0f} GB/s algorithmic ({gb / 1e6:.1f} MB)")
