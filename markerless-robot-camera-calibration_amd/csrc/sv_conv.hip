@@ -86,6 +86,10 @@ struct ConvCfg {
   static constexpr int GK = fused_offsets(CPO);  // kernel offsets per pipeline step
   static constexpr int KC = CPO ? (GK * CPO + 3) / 4 * 4 : chunk_for(TM_, WAVES_N);  // A columns per step
   static constexpr int SA = lds_row_stride(KC);  // A row stride in floats
+  // A-operand prefetch distance in k-steps: enough matrix work (MR * NT ops of 32 cycles) to cover ~250 cycles
+  // (big tiles, MR * NT >= 6: one k-step, their waves hide the rest behind each other)
+  static constexpr int PFD_RAW = MR * NT >= 6 ? 1 : (8 + MR * NT - 1) / (MR * NT);
+  static constexpr int PFD = PFD_RAW > KC / 4 ? KC / 4 : PFD_RAW;
   static constexpr int F4_PER_ROW = KC / 4;      // float4 per gathered row and step
   static constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
   static constexpr int A_F4 = (TM_ + ROWS_PER_PASS - 1) / ROWS_PER_PASS;  // float4 gathers per thread and step
@@ -99,10 +103,11 @@ struct ConvCfg {
 // FAST: float4 gathers, Cout a multiple of TN -> every load is unconditional (out-of-range lanes read a safe address and
 // are zeroed afterwards), so the loop body is straight-line and hipcc can emit COUNTED vmcnt waits; the generic
 // variant keeps per-lane guards (odd channel counts such as Cin = 3 or Cout = 3).
-template <int TM_, int WAVES_N, int NT, bool FAST, int CPO = 0>
+template <int TM_, int WAVES_N, int NT, bool FAST, int CPO = 0, bool RING = false>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
   using Cfg = ConvCfg<TM_, WAVES_N, NT, CPO>;
   constexpr int MR = Cfg::MR, TN = Cfg::TN, A_F4 = Cfg::A_F4, KC = Cfg::KC, SA = Cfg::SA, GK = Cfg::GK;
+  constexpr int PFD = RING ? Cfg::PFD : 1;  // RING: launches too small to fill the chip (see launch_conv)
   constexpr int ROWS_PER_PASS = Cfg::ROWS_PER_PASS;
   constexpr int SUBS = TM_ / 16;  // sub-tiles per tile
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -313,33 +318,63 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
       const int kb = have_n ? k_n : 0;
       const float* wnext = step_weights(kb, c_n);
       const int ksteps_next = ksteps_of(kb, c_n);
-      float a_cur[MR];
+      // A operands run PFD k-steps ahead of the matrix ops in a register ring: one k-step of a small tile is only
+      // MR * NT * 32 cycles of matrix work, less than an LDS round trip, and on the small pyramid levels a wave has
+      // no co-resident wave to hide that latency behind
+      if constexpr (PFD == 1) {
+        float a_cur[MR];
 #pragma unroll
-      for (int s = 0; s < MR; ++s) a_cur[s] = a_base[s * 16 * SA];
+        for (int s = 0; s < MR; ++s) a_cur[s] = a_base[s * 16 * SA];
 #pragma unroll
-      for (int ks = 0; ks < KC / 4; ++ks) {
-        if (ks < ksteps) {
-          float a_nx[MR];
-          if (ks + 1 < KC / 4) {
+        for (int ks = 0; ks < KC / 4; ++ks) {
+          if (ks < ksteps) {
+            float a_nx[MR];
+            if (ks + 1 < KC / 4) {
 #pragma unroll
-            for (int s = 0; s < MR; ++s) a_nx[s] = a_base[s * 16 * SA + (ks + 1) * 4];
-          }
+              for (int s = 0; s < MR; ++s) a_nx[s] = a_base[s * 16 * SA + (ks + 1) * 4];
+            }
 #pragma unroll
-          for (int s = 0; s < MR; ++s) {
-            // a tile with ONE sub-tile per wave row group is only visited for offsets where that sub-tile is active
-            // (steps with an empty submask are skipped), so the test is compile-time true there
-            if ((MR == 1 && Cfg::WAVES_M == 1) || ((smw >> s) & 1u)) {
+            for (int s = 0; s < MR; ++s) {
+              // a tile with ONE sub-tile per wave row group is only visited for offsets where that sub-tile is active
+              // (steps with an empty submask are skipped), so the test is compile-time true there
+              if ((MR == 1 && Cfg::WAVES_M == 1) || ((smw >> s) & 1u)) {
 #pragma unroll
-              for (int n = 0; n < NT; ++n)
-                acc[s][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], b[ks][n], acc[s][n], 0, 0, 0);
+                for (int n = 0; n < NT; ++n)
+                  acc[s][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], b[ks][n], acc[s][n], 0, 0, 0);
+              }
+            }
+            if (ks + 1 < KC / 4) {
+#pragma unroll
+              for (int s = 0; s < MR; ++s) a_cur[s] = a_nx[s];
             }
           }
-          if (ks + 1 < KC / 4) {
-#pragma unroll
-            for (int s = 0; s < MR; ++s) a_cur[s] = a_nx[s];
-          }
+          if (FAST || have_n) load_b(wnext, kb, c_n, ksteps_next, ks, b[ks]);
         }
-        if (FAST || have_n) load_b(wnext, kb, c_n, ksteps_next, ks, b[ks]);
+      } else {
+        float a_ring[PFD + 1][MR];
+#pragma unroll
+        for (int d = 0; d < PFD; ++d)
+#pragma unroll
+          for (int s = 0; s < MR; ++s) a_ring[d][s] = a_base[s * 16 * SA + d * 4];
+#pragma unroll
+        for (int ks = 0; ks < KC / 4; ++ks) {
+          if (ks < ksteps) {
+            if (ks + PFD < KC / 4) {
+#pragma unroll
+              for (int s = 0; s < MR; ++s) a_ring[(ks + PFD) % (PFD + 1)][s] = a_base[s * 16 * SA + (ks + PFD) * 4];
+            }
+#pragma unroll
+            for (int s = 0; s < MR; ++s) {
+              if ((MR == 1 && Cfg::WAVES_M == 1) || ((smw >> s) & 1u)) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                  acc[s][n] =
+                      __builtin_amdgcn_mfma_f32_16x16x4f32(a_ring[ks % (PFD + 1)][s], b[ks][n], acc[s][n], 0, 0, 0);
+              }
+            }
+          }
+          if (FAST || have_n) load_b(wnext, kb, c_n, ksteps_next, ks, b[ks]);
+        }
       }
       ++trace_steps;
       if (!have_n) break;
@@ -424,12 +459,24 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
   static const char* trace_path = getenv("SV_CONV_TRACE");
   q.trace = nullptr;
   if (trace_path) SV_HIP(hipMalloc((void**)&q.trace, (size_t)grid.x * 4 * sizeof(unsigned long long)));
-  if (CPO % 4 == 0 ? fast : false)  // odd channel counts (Cin = 3) only exist in the guarded form
-    hipLaunchKernelGGL((conv_fwd_kernel<TM_, WAVES_N, NT, (CPO % 4 == 0), CPO>), grid, dim3(256), Cfg::lds_bytes(p.K),
-                       stream, q);
-  else
-    hipLaunchKernelGGL((conv_fwd_kernel<TM_, WAVES_N, NT, false, CPO>), grid, dim3(256), Cfg::lds_bytes(p.K), stream,
-                       q);
+  // launches of at most ~4 workgroups per CU are bound by the latency of one wave's step chain, not by the matrix
+  // pipe: their waves read the A operands several k-steps ahead (register ring); fuller launches hide that latency
+  // behind co-resident waves and are a few % faster with the plain one-step-ahead read
+  const bool ring = Cfg::PFD > 1 && grid.x <= 1024;
+  constexpr bool F = (CPO % 4 == 0);  // odd channel counts (Cin = 3) only exist in the guarded form
+  const size_t lds = Cfg::lds_bytes(p.K);
+  if (F && fast) {
+    if (ring)
+      hipLaunchKernelGGL((conv_fwd_kernel<TM_, WAVES_N, NT, F, CPO, (Cfg::PFD > 1)>), grid, dim3(256), lds, stream, q);
+    else
+      hipLaunchKernelGGL((conv_fwd_kernel<TM_, WAVES_N, NT, F, CPO, false>), grid, dim3(256), lds, stream, q);
+  } else {
+    if (ring)
+      hipLaunchKernelGGL((conv_fwd_kernel<TM_, WAVES_N, NT, false, CPO, (Cfg::PFD > 1)>), grid, dim3(256), lds, stream,
+                         q);
+    else
+      hipLaunchKernelGGL((conv_fwd_kernel<TM_, WAVES_N, NT, false, CPO, false>), grid, dim3(256), lds, stream, q);
+  }
   SV_LAUNCH_CHECK();
   if (q.trace) {
     std::vector<unsigned long long> host((size_t)grid.x * 4);
