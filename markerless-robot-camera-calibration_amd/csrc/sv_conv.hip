@@ -15,6 +15,7 @@
 // A missing neighbour contributes fma(0, w, acc) = acc.
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 #include <vector>
 
 #include "sv_common.h"
@@ -51,6 +52,9 @@ struct ConvParams {
   unsigned long long* trace;  // SV_CONV_TRACE experiments: per-workgroup {start, end, hw id, steps}; null otherwise
 };
 
+#ifndef SV_SCHED_BARRIER
+#define SV_SCHED_BARRIER 1
+#endif
 constexpr int PLAN_TILE = SV_TILE_ROWS;  // plans (perm / nbr_s / submask) are laid out in 128-row tiles
 // input channels per pipeline step: short tiles (used on small pyramid levels, where a launch is bound by the latency
 // of a tile's sequential step chain) take wider chunks, i.e. fewer barriers / gather round trips per tile
@@ -90,6 +94,10 @@ struct ConvCfg {
   // (big tiles, MR * NT >= 6: one k-step, their waves hide the rest behind each other)
   static constexpr int PFD_RAW = MR * NT >= 6 ? 1 : (8 + MR * NT - 1) / (MR * NT);
   static constexpr int PFD = PFD_RAW > KC / 4 ? KC / 4 : PFD_RAW;
+  // the FULL form (see the kernel) pays where a k-step is one or two matrix ops and the per-k-step bookkeeping of
+  // the general form dominates; on the 64-row tile it costs the 129th VGPR (3 instead of 4 waves per SIMD) and on
+  // 16x128 tiles it measured slower (profiles/r01_conv_full_form.txt)
+  static constexpr bool USE_FULL = (MR * NT == 1) || (TM_ == 32 && WAVES_N == 4 && NT == 3);
   static constexpr int F4_PER_ROW = KC / 4;      // float4 per gathered row and step
   static constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
   static constexpr int A_F4 = (TM_ + ROWS_PER_PASS - 1) / ROWS_PER_PASS;  // float4 gathers per thread and step
@@ -103,8 +111,9 @@ struct ConvCfg {
 // FAST: float4 gathers, Cout a multiple of TN -> every load is unconditional (out-of-range lanes read a safe address and
 // are zeroed afterwards), so the loop body is straight-line and hipcc can emit COUNTED vmcnt waits; the generic
 // variant keeps per-lane guards (odd channel counts such as Cin = 3 or Cout = 3).
-template <int TM_, int WAVES_N, int NT, bool FAST, int CPO = 0, bool RING = false>
+template <int TM_, int WAVES_N, int NT, bool FAST, int CPO = 0, bool RING = false, bool FULL = false>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
+  static_assert(FAST || !FULL, "FULL is a refinement of the FAST form");
   using Cfg = ConvCfg<TM_, WAVES_N, NT, CPO>;
   constexpr int MR = Cfg::MR, TN = Cfg::TN, A_F4 = Cfg::A_F4, KC = Cfg::KC, SA = Cfg::SA, GK = Cfg::GK;
   constexpr int PFD = RING ? Cfg::PFD : 1;  // RING: launches too small to fill the chip (see launch_conv)
@@ -318,62 +327,77 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
       const int kb = have_n ? k_n : 0;
       const float* wnext = step_weights(kb, c_n);
       const int ksteps_next = ksteps_of(kb, c_n);
-      // A operands run PFD k-steps ahead of the matrix ops in a register ring: one k-step of a small tile is only
-      // MR * NT * 32 cycles of matrix work, less than an LDS round trip, and on the small pyramid levels a wave has
-      // no co-resident wave to hide that latency behind
-      if constexpr (PFD == 1) {
-        float a_cur[MR];
+      // A operands run PFD k-steps ahead of the matrix ops (register ring when PFD > 1): one k-step of a small tile is
+      // only MR * NT * 32 cycles of matrix work, less than an LDS round trip, and on the small pyramid levels a wave
+      // has no co-resident wave to hide that latency behind.
+      // FULL (every step uses all KC columns: Cin % KC == 0, chosen at launch): compile-time trip count and plain
+      // weight-row addressing, i.e. no per-k-step compare / select / branch in the hot loop.
+      {
+        auto reload_b = [&](int ks) {
+          if (FULL) {
+            const float* src = wnext + (int64_t)(4 * ks) * Cout;
 #pragma unroll
-        for (int s = 0; s < MR; ++s) a_cur[s] = a_base[s * 16 * SA];
+            for (int n = 0; n < NT; ++n) b[ks][n] = src[b_off + n];
+          } else if (FAST || have_n) {
+            load_b(wnext, kb, c_n, ksteps_next, ks, b[ks]);
+          }
+        };
+        auto mfma_row = [&](int ks, const float (&a)[MR]) {
 #pragma unroll
-        for (int ks = 0; ks < KC / 4; ++ks) {
-          if (ks < ksteps) {
-            float a_nx[MR];
-            if (ks + 1 < KC / 4) {
+          for (int s = 0; s < MR; ++s) {
+            // a tile with ONE sub-tile per wave row group is only visited for offsets where that sub-tile is active
+            // (steps with an empty submask are skipped), so the test is compile-time true there
+            if ((MR == 1 && Cfg::WAVES_M == 1) || ((smw >> s) & 1u)) {
 #pragma unroll
-              for (int s = 0; s < MR; ++s) a_nx[s] = a_base[s * 16 * SA + (ks + 1) * 4];
-            }
-#pragma unroll
-            for (int s = 0; s < MR; ++s) {
-              // a tile with ONE sub-tile per wave row group is only visited for offsets where that sub-tile is active
-              // (steps with an empty submask are skipped), so the test is compile-time true there
-              if ((MR == 1 && Cfg::WAVES_M == 1) || ((smw >> s) & 1u)) {
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                  acc[s][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], b[ks][n], acc[s][n], 0, 0, 0);
-              }
-            }
-            if (ks + 1 < KC / 4) {
-#pragma unroll
-              for (int s = 0; s < MR; ++s) a_cur[s] = a_nx[s];
+              for (int n = 0; n < NT; ++n)
+                acc[s][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[ks][n], acc[s][n], 0, 0, 0);
             }
           }
-          if (FAST || have_n) load_b(wnext, kb, c_n, ksteps_next, ks, b[ks]);
-        }
-      } else {
-        float a_ring[PFD + 1][MR];
+        };
+        if constexpr (PFD == 1) {
+          float a_cur[MR];
 #pragma unroll
-        for (int d = 0; d < PFD; ++d)
+          for (int s = 0; s < MR; ++s) a_cur[s] = a_base[s * 16 * SA];
 #pragma unroll
-          for (int s = 0; s < MR; ++s) a_ring[d][s] = a_base[s * 16 * SA + d * 4];
+          for (int ks = 0; ks < KC / 4; ++ks) {
+            if (FULL || ks < ksteps) {
+              float a_nx[MR];
+              if (ks + 1 < KC / 4) {
 #pragma unroll
-        for (int ks = 0; ks < KC / 4; ++ks) {
-          if (ks < ksteps) {
-            if (ks + PFD < KC / 4) {
+                for (int s = 0; s < MR; ++s) a_nx[s] = a_base[s * 16 * SA + (ks + 1) * 4];
+                if (FULL && SV_SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);  // operand reads go out first
+              }
+              mfma_row(ks, a_cur);
+              if (ks + 1 < KC / 4) {
 #pragma unroll
-              for (int s = 0; s < MR; ++s) a_ring[(ks + PFD) % (PFD + 1)][s] = a_base[s * 16 * SA + (ks + PFD) * 4];
-            }
-#pragma unroll
-            for (int s = 0; s < MR; ++s) {
-              if ((MR == 1 && Cfg::WAVES_M == 1) || ((smw >> s) & 1u)) {
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                  acc[s][n] =
-                      __builtin_amdgcn_mfma_f32_16x16x4f32(a_ring[ks % (PFD + 1)][s], b[ks][n], acc[s][n], 0, 0, 0);
+                for (int s = 0; s < MR; ++s) a_cur[s] = a_nx[s];
               }
             }
+            reload_b(ks);
+            // straight-line code (FULL): keep the written interleaving of operand reads, matrix ops and weight reloads -
+            // left alone, the scheduler batches the reloads behind all matrix ops and their latency is exposed
+            if (FULL && SV_SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);
           }
-          if (FAST || have_n) load_b(wnext, kb, c_n, ksteps_next, ks, b[ks]);
+        } else {
+          float a_ring[PFD + 1][MR];
+#pragma unroll
+          for (int d = 0; d < PFD; ++d)
+#pragma unroll
+            for (int s = 0; s < MR; ++s) a_ring[d][s] = a_base[s * 16 * SA + d * 4];
+#pragma unroll
+          for (int ks = 0; ks < KC / 4; ++ks) {
+            if (FULL || ks < ksteps) {
+              if (ks + PFD < KC / 4) {
+#pragma unroll
+                for (int s = 0; s < MR; ++s)
+                  a_ring[(ks + PFD) % (PFD + 1)][s] = a_base[s * 16 * SA + (ks + PFD) * 4];
+                if (FULL && SV_SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);
+              }
+              mfma_row(ks, a_ring[ks % (PFD + 1)]);
+            }
+            reload_b(ks);
+            if (FULL && SV_SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);
+          }
         }
       }
       ++trace_steps;
@@ -465,7 +489,14 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
   const bool ring = Cfg::PFD > 1 && grid.x <= 1024;
   constexpr bool F = (CPO % 4 == 0);  // odd channel counts (Cin = 3) only exist in the guarded form
   const size_t lds = Cfg::lds_bytes(p.K);
-  if (F && fast) {
+  // FULL: no partial channel chunk anywhere in the layer
+  const bool full = Cfg::USE_FULL && (CPO ? (p.K % Cfg::GK == 0) : (p.Cin % Cfg::KC == 0));
+  if (F && fast && full) {
+    if (ring)
+      hipLaunchKernelGGL((conv_fwd_kernel<TM_, WAVES_N, NT, F, CPO, (Cfg::PFD > 1), (F && Cfg::USE_FULL)>), grid, dim3(256), lds, stream, q);
+    else
+      hipLaunchKernelGGL((conv_fwd_kernel<TM_, WAVES_N, NT, F, CPO, false, (F && Cfg::USE_FULL)>), grid, dim3(256), lds, stream, q);
+  } else if (F && fast) {
     if (ring)
       hipLaunchKernelGGL((conv_fwd_kernel<TM_, WAVES_N, NT, F, CPO, (Cfg::PFD > 1)>), grid, dim3(256), lds, stream, q);
     else
