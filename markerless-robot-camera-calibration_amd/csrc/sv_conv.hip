@@ -354,7 +354,34 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
             }
           }
         };
-        if constexpr (PFD == 1) {
+        if constexpr (PFD == 1 && !FULL) {
+          float a_cur[MR];
+#pragma unroll
+          for (int s = 0; s < MR; ++s) a_cur[s] = a_base[s * 16 * SA];
+#pragma unroll
+          for (int ks = 0; ks < KC / 4; ++ks) {
+            if (ks < ksteps) {
+              float a_nx[MR];
+              if (ks + 1 < KC / 4) {
+#pragma unroll
+                for (int s = 0; s < MR; ++s) a_nx[s] = a_base[s * 16 * SA + (ks + 1) * 4];
+              }
+#pragma unroll
+              for (int s = 0; s < MR; ++s) {
+                if ((MR == 1 && Cfg::WAVES_M == 1) || ((smw >> s) & 1u)) {
+#pragma unroll
+                  for (int n = 0; n < NT; ++n)
+                    acc[s][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], b[ks][n], acc[s][n], 0, 0, 0);
+                }
+              }
+              if (ks + 1 < KC / 4) {
+#pragma unroll
+                for (int s = 0; s < MR; ++s) a_cur[s] = a_nx[s];
+              }
+            }
+            if (FAST || have_n) load_b(wnext, kb, c_n, ksteps_next, ks, b[ks]);
+          }
+        } else if constexpr (PFD == 1) {
           float a_cur[MR];
 #pragma unroll
           for (int s = 0; s < MR; ++s) a_cur[s] = a_base[s * 16 * SA];
