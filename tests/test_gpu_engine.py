@@ -218,3 +218,33 @@ def test_evaluation_harness_end_to_end(gpu):
         assert out2["instances"] == {}  # every frame fails the EE-count threshold, as in app/test.py:110-113
     finally:
         Config.reset()
+
+
+def test_rccl_metrics_gather_single_rank(gpu):
+    """The run's one collective on the real backend: RCCL (backend "nccl") all_gather of the float64 metrics record.
+    One rank is all a 1-GPU box allows; the 2-rank exchange itself is covered on gloo in tests/test_dist_cpu.py."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+    from mrcc_amd.app import sharding
+
+    if dist.is_initialized():
+        pytest.skip("process group already initialised")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        vec = torch.arange(13, dtype=torch.float64, device="cuda")
+        parts = [torch.zeros_like(vec)]
+        dist.all_gather(parts, vec)
+        dist.barrier()
+        assert torch.equal(parts[0], vec)
+        agg = sharding.gather_metrics({"frames": 3, "elapsed": 0.5, "confusion": np.eye(3, dtype=np.int64), "seed_sum": 7},
+                                      device="cuda")
+        assert agg["frames"] == 3 and agg["elapsed_max"] == 0.5 and agg["seed_sum"] == 7
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,47 @@
+"""gpurun_out/traffic/traffic_raw.json (tools/pmc_traffic.sh) -> profiles/r01_traffic.json.
+
+FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE under-reports this kernel's row gathers, so both are scaled by the factors
+measured on the known-traffic launch (tools/traffic_calib.py), as the MI355X guide's HBM/rocprofv3 section prescribes.
+Kernel names are folded to bench.py's naming: conv_fwd_kernel<TM, WAVES_N, NT[, fused Cin]>."""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+raw = json.load(open(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out/traffic/traffic_raw.json")))
+
+
+def fold(name):
+    m = re.search(r"conv_fwd_kernel<([^>]*)>", name)
+    a = [x.strip() for x in m.group(1).split(",")]
+    cpo = int(a[4]) if len(a) > 4 else 0
+    return f"conv_fwd_kernel<{a[0]}, {a[1]}, {a[2]}" + (f", fused {cpo}>" if cpo else ">")
+
+
+known = raw["known"]
+(cal_name, cal), = [(k, v) for k, v in raw["calibration"].items() if "FETCH_SIZE" in v][:1]
+ff = known["read_bytes"] / (cal["FETCH_SIZE"] * 1024)
+wf = known["write_bytes"] / (cal["WRITE_SIZE"] * 1024)
+out = {
+    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --steps 6 --warmup 2 --streams 1`",
+    "calibration": {"kernel": fold(cal_name), "known_read_bytes": known["read_bytes"],
+                    "known_write_bytes": known["write_bytes"], "FETCH_SIZE_KB": cal["FETCH_SIZE"],
+                    "WRITE_SIZE_KB": cal["WRITE_SIZE"], "fetch_factor": round(ff, 4), "write_factor": round(wf, 4),
+                    "note": "dense 1x1 launch reading 3.07 GB / writing 1.54 GB exactly once (tools/traffic_calib.py); "
+                            "FETCH_SIZE * 1024 under-reports the 16 B/lane row gathers by fetch_factor, WRITE_SIZE is exact"},
+    "kernels": {},
+}
+acc = {}
+for name, b in raw["bench"].items():
+    k = fold(name)
+    n = b["FETCH_SIZE"]["launches"]
+    d = acc.setdefault(k, [0, 0.0, 0.0])
+    d[0] += n
+    d[1] += b["FETCH_SIZE"]["per_launch"] * n * 1024 * ff
+    d[2] += b["WRITE_SIZE"]["per_launch"] * n * 1024 * wf
+for k, (n, r, w) in sorted(acc.items()):
+    out["kernels"][k] = {"launches": n, "read_GB_per_launch": round(r / n / 1e9, 4),
+                         "write_GB_per_launch": round(w / n / 1e9, 4), "traffic_GB_per_launch": round((r + w) / n / 1e9, 4)}
+json.dump(out, open(os.path.join(ROOT, "profiles", "r01_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
