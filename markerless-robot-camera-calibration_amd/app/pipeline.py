@@ -9,6 +9,7 @@ Prepared frames are kept alive until the compute stream has finished with them, 
 recycle their memory under a running kernel.
 """
 import collections
+import os
 
 import torch
 
@@ -39,7 +40,10 @@ class FramePipeline:
         self.device = torch.device(device)
         self.levels = levels
         self.encoder_only = encoder_only
-        self.prep_stream = torch.cuda.Stream(device=self.device)
+        # the prep stream's ~150 small kernels per frame must not queue behind thousands of conv workgroups: the host
+        # blocks on their size read-backs, and a late prepare() starves a compute stream (high priority = -1)
+        prio = int(os.environ.get("MRCC_PREP_PRIORITY", "-1"))
+        self.prep_stream = torch.cuda.Stream(device=self.device, priority=prio)
         # compute_streams > 1: consecutive frames run on alternating streams, so the small-pyramid-level and thin-layer
         # kernels of one frame (which cannot fill 256 CUs) overlap the big convolutions of its neighbour
         self.compute_streams = [torch.cuda.Stream(device=self.device) for _ in range(compute_streams)] \

@@ -12,7 +12,7 @@ frames = [bench.make_frame(i, dev) for i in range(4)]
 pipe = FramePipeline(dev, levels=4, compute_streams=streams)
 t_start = time.perf_counter()
 with torch.no_grad():
-    for blk in range(20):
+    for blk in range(int(sys.argv[2]) if len(sys.argv) > 2 else 20):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         bench.run_frames(model, pipe, frames, 10)
         pipe.drain(); torch.cuda.synchronize()
