@@ -607,7 +607,8 @@ static int select_and_launch(const ConvParams& p, hipStream_t stream) {
   // duration is the serial (offset, chunk) chain of one of them: 16-row tiles with 128-channel chunks are fastest
   // there (tools/sweep_small.sh, profiles/r01_conv_small_level_sweep.txt).
   static const Candidate wide3[] = {{64, 4, 3, 2500}, {32, 4, 3, 1500}, {32, 2, 3, 0}};
-  static const Candidate wide3_128[] = {{64, 4, 3, 2500}, {32, 4, 3, 1500}, {16, 4, 2, 0}};  // Cout % 128 == 0
+  // Cout % 128 == 0 (384): settled-clock sweep of the mid levels, profiles/r01_conv_mid_level_sweep.txt
+  static const Candidate wide3_128[] = {{64, 4, 3, 2500}, {64, 4, 2, 1200}, {16, 4, 3, 800}, {16, 4, 2, 0}};
   static const Candidate wide2[] = {{128, 4, 2, 1300}, {64, 4, 2, 1500}, {32, 4, 2, 1500}, {32, 2, 2, 0}};
   static const Candidate wide2_64[] = {{128, 4, 2, 1300}, {64, 4, 2, 1500}, {32, 4, 2, 1500}, {16, 4, 1, 0}};  // % 64
   static const Candidate c64[] = {{64, 4, 1, 1500}, {32, 4, 1, 1500}, {16, 4, 1, 0}};
@@ -616,7 +617,7 @@ static int select_and_launch(const ConvParams& p, hipStream_t stream) {
   const Candidate* list;
   int n;
   const int Cout = p.Cout;
-  if (Cout > 128 && (Cout % 192 == 0 || Cout % 96 == 0 || Cout > 2048)) { list = Cout % 128 == 0 ? wide3_128 : wide3; n = 3; }
+  if (Cout > 128 && (Cout % 192 == 0 || Cout % 96 == 0 || Cout > 2048)) { list = Cout % 128 == 0 ? wide3_128 : wide3; n = Cout % 128 == 0 ? 4 : 3; }
   else if (Cout > 64) { list = Cout % 64 == 0 ? wide2_64 : wide2; n = 4; }
   else if (Cout > 32) { list = c64; n = 3; }
   else if (Cout > 16) { list = c32; n = 3; }
