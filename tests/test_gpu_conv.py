@@ -27,8 +27,8 @@ def _same(a, b):
     return np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("cin,cout", [(3, 32), (32, 32), (32, 64), (64, 128), (96, 384), (416, 384), (7, 5),
-                                      (130, 200)])
+@pytest.mark.parametrize("cin,cout", [(3, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (256, 256),
+                                      (96, 384), (384, 384), (416, 384), (7, 5), (130, 200)])
 def test_conv_k3_bit_exact(gpu, oracle, cin, cout):
     from mrcc_amd import nn as svnn
 
@@ -105,3 +105,36 @@ def test_strided_input_and_affine(gpu, oracle):
     b = rng.normal(size=96).astype(np.float32)
     got = svnn.affine_act(tb, torch.from_numpy(s).to(gpu), torch.from_numpy(b).to(gpu), act=2, slope=0.01)
     assert _same(got.cpu().numpy(), oracle.affine_act(big, s, b, None, oracle.ACT_LEAKY, 0.01))
+
+
+@pytest.mark.parametrize("level,cin", [(0, 32), (1, 64), (2, 96), (3, 128)])
+def test_conv_every_tile_shape_of_the_pyramid_bit_exact(gpu, oracle, level, cin):
+    """The Cfg-2 pyramid (88k / 26k / 7k / 2k voxels) with 384 output channels walks the dispatch table of the wide
+    layers: 64x192, 64x128, 16x192 and 16x128 (register-ring) tiles.  Narrow inputs keep the oracle fast."""
+    import mrcc_amd
+    from mrcc_amd import MinkowskiEngine as ME
+    from mrcc_amd import nn as svnn
+    from mrcc_amd import profiling
+
+    pts, rgb, _ = mrcc_amd.synth.gen_room(200_000, 2.4, 0)
+    coords4 = np.concatenate([np.zeros((len(pts), 1), np.float32), pts * np.float32(50)], axis=1)
+    st = ME.TensorField(torch.from_numpy(rgb), torch.from_numpy(coords4), device=gpu).sparse()
+    cm = st.coordinate_manager
+    ts = 1 << level
+    plan = cm.plan_k3(ts)
+    V = cm.stride_map(ts).V
+    expect = {0: "conv_fwd_kernel<64, 4, 3>", 1: "conv_fwd_kernel<64, 4, 2>", 2: "conv_fwd_kernel<16, 4, 3>",
+              3: "conv_fwd_kernel<16, 4, 2>"}[level]
+    assert profiling.conv_kernel_config(384, plan.Vpad, cin, 27) == expect
+    frame = oracle.Frame(oracle.voxelize(coords4)["coords"])
+    for l in range(level):
+        frame.down(1 << l)
+    rng = np.random.default_rng(level)
+    x = rng.normal(size=(V, cin)).astype(np.float32)
+    W = (rng.normal(size=(27, cin, 384)) * 0.05).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, size=384).astype(np.float32)
+    shift = rng.normal(size=384).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(gpu)
+    got = svnn.conv_forward(t(x), t(W), plan, V, t(scale), t(shift), None, 1).cpu().numpy()
+    want = oracle.conv(x, W, frame.k3(ts), V, scale, shift, None, oracle.ACT_RELU)
+    assert _same(got, want), f"max abs diff {np.abs(got - want).max()}"
