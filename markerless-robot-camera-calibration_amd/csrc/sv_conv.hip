@@ -4,10 +4,12 @@
 // MinkowskiBatchNorm(eval) (+ residual) (+ ReLU / LeakyReLU): model/backbone/minkunet.py:125-187,
 // model/backbone/resnet.py:95-127 (BasicBlock via ME), model/robotnet_segmentation.py:55-64.
 //
-// Work decomposition
-//   * a workgroup (4 waves) owns one tile of 128 output rows (in the plan's mask-sorted order) x TN output channels;
-//   * it walks the kernel offsets k in ASCENDING order and, per offset, the input channels in ascending chunks of 32;
-//   * per chunk the gathered input rows (A, 128 x 32) and the weight slab (B, 32 x TN) are staged in LDS;
+// Work decomposition (details at ConvCfg / conv_fwd_kernel below, measurements in DESIGN.md 4.1)
+//   * a workgroup (4 waves) owns one tile of TM output rows (in the plan's mask-sorted order) x TN output channels;
+//   * it walks pipeline steps = (kernel offset k ASCENDING, input-channel chunk ascending); thin layers fuse several
+//     offsets into one step;
+//   * per step the gathered input rows (A, TM x KC) go global -> registers -> LDS (double buffered, one barrier per
+//     step); the weights (B, KC x TN) go straight from L2/HBM to registers;
 //   * each wave multiplies with v_mfma_f32_16x16x4_f32; a 16-row sub-tile is skipped for an offset when none of its rows
 //     has a neighbour there (plan submask), which is what makes the mask-sorted row order pay.
 // Numerics: every output element is ONE f32 fma chain over (k ascending, c ascending) — the MFMA is a k-ordered
@@ -46,15 +48,11 @@ struct ConvParams {
   float* out;
   int64_t out_ld;
   int vec_a;  // in_ld % 4 == 0 && Cin % 4 == 0 && base aligned -> float4 gathers
-  int vec_b;  // Cout % 4 == 0 && W aligned -> float4 weight loads
   int ntiles;
   int ny;
   unsigned long long* trace;  // SV_CONV_TRACE experiments: per-workgroup {start, end, hw id, steps}; null otherwise
 };
 
-#ifndef SV_SCHED_BARRIER
-#define SV_SCHED_BARRIER 1
-#endif
 constexpr int PLAN_TILE = SV_TILE_ROWS;  // plans (perm / nbr_s / submask) are laid out in 128-row tiles
 // input channels per pipeline step: short tiles (used on small pyramid levels, where a launch is bound by the latency
 // of a tile's sequential step chain) take wider chunks, i.e. fewer barriers / gather round trips per tile
@@ -105,12 +103,15 @@ struct ConvCfg {
   static constexpr size_t lds_bytes(int K) { return (size_t)(2 * TM_ * SA + K * TM_) * sizeof(float); }
 };
 
-// One pipeline step = (kernel offset k, input-channel chunk c0), visited in ascending (k, c0) order.
-//   A (gathered rows, TM_ x 32): global -> registers one step ahead -> LDS (double buffered), one barrier per step.
-//   B (weights, 32 x TN): global -> registers, re-loaded for the next step right after their last use.
+// One pipeline step = (kernel offset k, input-channel chunk c0), visited in ascending (k, c0) order (CPO > 0: GK
+// consecutive offsets x all Cin channels per step).
+//   A (gathered rows, TM_ x KC): global -> registers one step ahead -> LDS (double buffered), one barrier per step.
+//   B (weights, KC x TN): global -> registers, re-loaded for the next step right after their last use.
 // FAST: float4 gathers, Cout a multiple of TN -> every load is unconditional (out-of-range lanes read a safe address and
-// are zeroed afterwards), so the loop body is straight-line and hipcc can emit COUNTED vmcnt waits; the generic
-// variant keeps per-lane guards (odd channel counts such as Cin = 3 or Cout = 3).
+//   are zeroed afterwards), so the loop body is straight-line and hipcc can emit COUNTED vmcnt waits; the generic
+//   variant keeps per-lane guards (odd channel counts such as Cin = 3 or Cout = 3).
+// RING: A operands are read PFD k-steps ahead of the matrix ops through a register ring (launches of few workgroups).
+// FULL: no partial chunk in the layer -> compile-time trip count and plain weight addressing in the matrix loop.
 template <int TM_, int WAVES_N, int NT, bool FAST, int CPO = 0, bool RING = false, bool FULL = false>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
   static_assert(FAST || !FULL, "FULL is a refinement of the FAST form");
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
               if (ks + 1 < KC / 4) {
 #pragma unroll
                 for (int s = 0; s < MR; ++s) a_nx[s] = a_base[s * 16 * SA + (ks + 1) * 4];
-                if (FULL && SV_SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);  // operand reads go out first
+                if (FULL) __builtin_amdgcn_sched_barrier(0);  // operand reads go out first
               }
               mfma_row(ks, a_cur);
               if (ks + 1 < KC / 4) {
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
             reload_b(ks);
             // straight-line code (FULL): keep the written interleaving of operand reads, matrix ops and weight reloads -
             // left alone, the scheduler batches the reloads behind all matrix ops and their latency is exposed
-            if (FULL && SV_SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);
+            if (FULL) __builtin_amdgcn_sched_barrier(0);
           }
         } else {
           float a_ring[PFD + 1][MR];
@@ -418,12 +419,12 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
 #pragma unroll
                 for (int s = 0; s < MR; ++s)
                   a_ring[(ks + PFD) % (PFD + 1)][s] = a_base[s * 16 * SA + (ks + PFD) * 4];
-                if (FULL && SV_SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);
+                if (FULL) __builtin_amdgcn_sched_barrier(0);
               }
               mfma_row(ks, a_ring[ks % (PFD + 1)]);
             }
             reload_b(ks);
-            if (FULL && SV_SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);
+            if (FULL) __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
@@ -669,7 +670,6 @@ extern "C" int sv_conv_fwd(const float* in, int64_t in_ld, int Cin, const float*
   p.scale = scale; p.shift = shift; p.residual = residual; p.res_ld = res_ld;
   p.act = act; p.slope = slope; p.out = out; p.out_ld = out_ld;
   p.vec_a = (in_ld % 4 == 0) && (Cin % 4 == 0) && (((uintptr_t)in & 15) == 0);
-  p.vec_b = (Cout % 4 == 0) && (((uintptr_t)W & 15) == 0);
   p.ntiles = 0;
   p.ny = 0;
   p.trace = nullptr;
