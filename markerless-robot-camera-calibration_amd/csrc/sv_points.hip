@@ -80,6 +80,110 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restric
   }
 }
 
+// max of a 64-bit key over one row of 16 lanes (result in lane 15 of the row) and over the wave (result in lane 63):
+// DPP row shifts / row broadcasts instead of ds_bpermute shuffles (a dozen dependent LDS-crossbar round trips per
+// iteration were most of an FPS iteration).  Lanes without a source read the identity 0.
+__device__ __forceinline__ unsigned long long dpp_max_step(unsigned long long k, unsigned long long o) {
+  return o > k ? o : k;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_fetch(unsigned long long k) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)k, CTRL, ROW_MASK, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(k >> 32), CTRL, ROW_MASK, 0xf, false);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long row_max16(unsigned long long k) {
+  k = dpp_max_step(k, dpp_fetch<0x111, 0xf>(k));  // row_shr:1
+  k = dpp_max_step(k, dpp_fetch<0x112, 0xf>(k));  // row_shr:2
+  k = dpp_max_step(k, dpp_fetch<0x114, 0xf>(k));  // row_shr:4
+  k = dpp_max_step(k, dpp_fetch<0x118, 0xf>(k));  // row_shr:8
+  return k;
+}
+__device__ __forceinline__ unsigned long long wave_max64(unsigned long long k) {
+  k = row_max16(k);
+  k = dpp_max_step(k, dpp_fetch<0x142, 0xa>(k));  // row_bcast:15 -> rows 1, 3
+  k = dpp_max_step(k, dpp_fetch<0x143, 0xc>(k));  // row_bcast:31 -> rows 2, 3
+  return k;  // lane 63
+}
+__device__ __forceinline__ unsigned long long read_lane64(unsigned long long k, int lane) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k, lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), lane);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// Register-resident variant for clouds of at most PPT * 1024 points: coordinates and running min-distances stay in
+// VGPRs (thread t owns points t, t + 1024, ...), an iteration touches no memory except the 16-entry cross-wave argmax
+// exchange (double-buffered in LDS, so ONE barrier per iteration; every wave reduces the 16 entries redundantly and
+// reads the winner's coordinates from an LDS copy of the cloud).
+// Same arithmetic and tie rule as fps_kernel.
+template <int PPT, bool LDS_XYZ>
+__global__ __launch_bounds__(FPS_THREADS) void fps_reg_kernel(const float* __restrict__ xyz, int N, int S,
+                                                               const int64_t* __restrict__ start,
+                                                               int64_t* __restrict__ out) {
+  constexpr int NW = FPS_THREADS / 64;
+  static_assert(NW == 16, "the cross-wave reduction is one 16-lane row");
+  __shared__ unsigned long long red_k[2][NW];
+  extern __shared__ __attribute__((aligned(16))) float xyz_s[];  // [3 N] when LDS_XYZ
+  const int b = blockIdx.x;
+  const float* P = xyz + (int64_t)b * N * 3;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (LDS_XYZ) {
+    for (int i = tid; i < 3 * N; i += FPS_THREADS) xyz_s[i] = P[i];
+    __syncthreads();
+  }
+  float px[PPT], py[PPT], pz[PPT], dm[PPT];
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    const int i = tid + j * FPS_THREADS;
+    const bool ok = i < N;
+    px[j] = ok ? P[i * 3] : 0.0f;
+    py[j] = ok ? P[i * 3 + 1] : 0.0f;
+    pz[j] = ok ? P[i * 3 + 2] : 0.0f;
+    dm[j] = ok ? 1e10f : -2.0f;  // padding never wins the argmax (real distances are >= 0 > -1)
+  }
+  int64_t s0 = start ? start[b] : 0;
+  int cur = (int)(s0 < 0 ? 0 : (s0 >= N ? N - 1 : s0));
+  float cx = P[cur * 3], cy = P[cur * 3 + 1], cz = P[cur * 3 + 2];
+  for (int it = 0; it < S; ++it) {
+    if (tid == 0) out[(int64_t)b * S + it] = cur;
+    float best = -1.0f;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const float dx = px[j] - cx, dy = py[j] - cy, dz = pz[j] - cz;
+      const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      if (d < dm[j]) dm[j] = d;
+      if (dm[j] > best) {  // strictly greater: the lowest index wins within a thread (indices ascend with j)
+        best = dm[j];
+        bi = tid + j * FPS_THREADS;
+      }
+    }
+    // argmax as the maximum of the key (distance bits, ~index): distances are >= 0, so their bit patterns order like
+    // the floats, and among equal distances the lowest index has the largest key; padding (best < 0) maps to key 0
+    unsigned long long key = best < 0.0f ? 0ull
+                                         : (((unsigned long long)__float_as_uint(best)) << 32) | (unsigned)(~bi);
+    key = read_lane64(wave_max64(key), 63);
+    const int buf = it & 1;
+    if (lane == 0) red_k[buf][wid] = key;
+    __syncthreads();
+    // every wave reduces the NW partial results itself (one row of 16 lanes)
+    unsigned long long k2 = lane < NW ? red_k[buf][lane] : 0ull;
+    k2 = read_lane64(row_max16(k2), 15);
+    const int ix = (int)~(unsigned)k2;
+    cur = __builtin_amdgcn_readfirstlane(ix);
+    // coordinates of the winner: from the LDS copy of the cloud when it fits, else from global memory (cached)
+    if (LDS_XYZ) {
+      cx = xyz_s[cur * 3];
+      cy = xyz_s[cur * 3 + 1];
+      cz = xyz_s[cur * 3 + 2];
+    } else {
+      cx = P[cur * 3];
+      cy = P[cur * 3 + 1];
+      cz = P[cur * 3 + 2];
+    }
+  }
+}
+
 // 4 waves per block, one query centre per wave
 __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict__ xyz,
                                                           const float* __restrict__ new_xyz, int B, int N, int S,
@@ -129,6 +233,31 @@ int sv_fps(const float* xyz, int B, int N, int S, const int64_t* start, int64_t*
   SV_CHECK_ARG((size_t)N * sizeof(float) <= 150 * 1024, "N too large for the LDS-resident distance array (38400)");
   if (B == 0) return SV_OK;
   SV_CHECK_ARG(xyz && out, "null pointer");
+  if (N <= 16 * FPS_THREADS) {  // register-resident cloud
+    static bool reg_attr_set = false;
+    if (!reg_attr_set) {
+      SV_HIP(hipFuncSetAttribute((const void*)fps_reg_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 150 * 1024));
+      SV_HIP(hipFuncSetAttribute((const void*)fps_reg_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 150 * 1024));
+      SV_HIP(hipFuncSetAttribute((const void*)fps_reg_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 150 * 1024));
+      reg_attr_set = true;
+    }
+    const size_t xyz_bytes = (size_t)N * 3 * sizeof(float);
+    const bool lds_xyz = xyz_bytes <= 150 * 1024;
+    const dim3 g((unsigned)B), t(FPS_THREADS);
+    if (N <= 4 * FPS_THREADS)
+      hipLaunchKernelGGL((fps_reg_kernel<4, true>), g, t, xyz_bytes, stream, xyz, N, S, start, out);
+    else if (N <= 8 * FPS_THREADS)
+      hipLaunchKernelGGL((fps_reg_kernel<8, true>), g, t, xyz_bytes, stream, xyz, N, S, start, out);
+    else if (lds_xyz)
+      hipLaunchKernelGGL((fps_reg_kernel<16, true>), g, t, xyz_bytes, stream, xyz, N, S, start, out);
+    else
+      hipLaunchKernelGGL((fps_reg_kernel<16, false>), g, t, 0, stream, xyz, N, S, start, out);
+    SV_LAUNCH_CHECK();
+    return SV_OK;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     SV_HIP(hipFuncSetAttribute((const void*)fps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));

@@ -80,6 +80,21 @@ def test_fps_vs_reference_golden(gpu, golden):
     assert np.array_equal(got.cpu().numpy(), g["t_idx"])
 
 
+@pytest.mark.parametrize("N,S", [(700, 64), (4096, 256), (8192, 300), (16384, 128), (20000, 96)])
+def test_fps_every_kernel_variant_matches_oracle(gpu, oracle, N, S):
+    """Register-resident FPS (4 / 8 / 16 points per thread) and the LDS fallback (N > 16384) give the oracle's index
+    sequence, ties included (duplicated points force equal distances)."""
+    from mrcc_amd.model import pointnet2_utils as P2
+
+    rng = np.random.default_rng(N)
+    xyz = rng.uniform(-1, 1, size=(3, N, 3)).astype(np.float32)
+    xyz[:, N // 2:N // 2 + 50] = xyz[:, :50]  # exact duplicates -> argmax ties
+    start = np.array([0, N - 1, N // 3], dtype=np.int64)
+    got = P2.farthest_point_sample(torch.from_numpy(xyz).to(gpu), S, start=torch.from_numpy(start).to(gpu))
+    want = oracle.farthest_point_sample(xyz, S, start)
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
 def test_ball_query_vs_reference_golden(gpu, golden):
     from mrcc_amd.model import pointnet2_utils as P2
 
