@@ -4,8 +4,9 @@
 //                   kernel launches) and utils/data.py:13-34 get_farthest_point_sample_idx (numpy)
 //  sv_ball_query <- model/pointnet2_utils.py:89-109 query_ball_point (full [B,S,N] distance matrix + sort)
 //
-// FPS: one workgroup per cloud; the running min-distance lives in LDS, each iteration is one pass over the cloud
-// plus a wave-shuffle + LDS argmax (first maximum wins, like numpy/torch argmax on CPU).
+// FPS: one workgroup per cloud, S sequential argmax rounds (first maximum wins, like numpy/torch argmax on CPU).
+// Up to 16k points the cloud and the running min-distances live in registers and a round is a DPP argmax + one
+// barrier (fps_reg_kernel); larger clouds keep the distances in LDS and re-read the points (fps_kernel).
 // Ball query: one wavefront per query centre scans the cloud in index order, 64 points per step, and compacts the
 // hits with ballot/popcount — no distance matrix, no sort.
 #include "sv_common.h"
