@@ -614,7 +614,7 @@ static int select_and_launch(const ConvParams& p, hipStream_t stream) {
   static const Candidate wide2_64[] = {{128, 4, 2, 1300}, {64, 4, 2, 1500}, {32, 4, 2, 1500}, {16, 4, 1, 0}};  // % 64
   static const Candidate c64[] = {{64, 4, 1, 1500}, {32, 4, 1, 1500}, {16, 4, 1, 0}};
   static const Candidate c32[] = {{128, 2, 1, 1500}, {64, 2, 1, 1500}, {32, 2, 1, 0}};
-  static const Candidate c16[] = {{128, 1, 1, 1500}, {64, 1, 1, 0}};
+  static const Candidate c16[] = {{128, 1, 1, 600}, {64, 1, 1, 0}};
   const Candidate* list;
   int n;
   const int Cout = p.Cout;

@@ -16,7 +16,7 @@ _CANDIDATES = {
     "wide2_64": [(128, 4, 2, 1300), (64, 4, 2, 1500), (32, 4, 2, 1500), (16, 4, 1, 0)],
     "c64": [(64, 4, 1, 1500), (32, 4, 1, 1500), (16, 4, 1, 0)],
     "c32": [(128, 2, 1, 1500), (64, 2, 1, 1500), (32, 2, 1, 0)],
-    "c16": [(128, 1, 1, 1500), (64, 1, 1, 0)],
+    "c16": [(128, 1, 1, 600), (64, 1, 1, 0)],
 }
 
 
