@@ -58,10 +58,15 @@ def build_model(device):
     return model.to(device).eval()
 
 
-def make_frame(seed, device, n=POINTS, L=ROOM):
-    pts, rgb, lab = mrcc_amd.synth.gen_room(n, L, seed)
-    coords4 = np.concatenate([np.zeros((n, 1), np.float32), pts * np.float32(SCALE)], axis=1)
-    return (torch.from_numpy(coords4).to(device), torch.from_numpy(rgb).to(device), pts, rgb, lab)
+def make_frame(seed, device, n=POINTS, L=ROOM, batch=1):
+    """One step's input: `batch` frames of n points in the reference's batched format (batch index in column 0,
+    data/alivev2.py:358-383); batch = 1 is the headline workload."""
+    parts = [mrcc_amd.synth.gen_room(n, L, seed * batch + b) for b in range(batch)]
+    coords4 = np.concatenate([np.concatenate([np.full((n, 1), b, np.float32), p[0] * np.float32(SCALE)], axis=1)
+                              for b, p in enumerate(parts)])
+    rgb = np.concatenate([p[1] for p in parts])
+    return (torch.from_numpy(coords4).to(device), torch.from_numpy(rgb).to(device), parts[0][0], parts[0][1],
+            parts[0][2])
 
 
 def run_frames(model, pipe, frames, steps, hist=None):
@@ -132,6 +137,8 @@ def main():
     ap.add_argument("--pool", type=int, default=4, help="distinct frames resident per rank")
     ap.add_argument("--no-kernel-timer", action="store_true", help="diagnostic: drop the per-launch HIP events")
     ap.add_argument("--streams", type=int, default=2, help="compute streams alternating between frames (1 = single)")
+    ap.add_argument("--frames-per-step", type=int, default=1,
+                    help="frames fused into one sparse tensor per step (batch column); 1 = the headline workload")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -154,7 +161,7 @@ def main():
 
     model = build_model(device)
     # rank r owns frames r, r + world, ... of the global seed sequence (Cfg-4 sharding rule)
-    frames = [make_frame(rank + world * i, device) for i in range(args.pool)]
+    frames = [make_frame(rank + world * i, device, batch=args.frames_per_step) for i in range(args.pool)]
 
     def barrier():
         if world > 1:
@@ -202,11 +209,11 @@ def main():
     from mrcc_amd.app.sharding import gather_metrics
 
     h = hist.cpu().numpy()
-    agg = gather_metrics({"frames": args.steps, "elapsed": elapsed, "confusion": np.diag(h), "seed_sum": voxels},
+    agg = gather_metrics({"frames": args.steps * args.frames_per_step, "elapsed": elapsed, "confusion": np.diag(h), "seed_sum": voxels},
                          device=device if backend == "nccl" else "cpu")
     t_max = agg["elapsed_max"]
     total_frames = float(agg["frames"])
-    voxels_per_frame = voxels // max(args.steps, 1)
+    voxels_per_frame = voxels // max(args.steps * args.frames_per_step, 1)
 
     if rank == 0:
         ksum = timer.summarize()
@@ -249,7 +256,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "cfg2: synthetic 200k-pt RGB-D cloud, 2 cm voxels, RobotNetSegmentation(MinkUNet18D) "
                                    "forward = voxelise + sparse U-Net + slice/argmax, random-init weights",
-                       "points_per_frame": POINTS, "voxel_size_m": 1.0 / SCALE,
+                       "points_per_frame": POINTS, "frames_per_step": args.frames_per_step,
+                       "voxel_size_m": 1.0 / SCALE,
                        "active_voxels_per_frame": int(voxels_per_frame),
                        "label_histogram": [int(x) for x in np.diag(agg["confusion"])],
                        "parallelism": f"frame-sharded x{world}, one RCCL all_gather of metrics; per rank: prep stream + "
