@@ -498,6 +498,105 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
   }
 }
 
+// ---- narrow-output dense layer (K = 1, identity rows, Cout <= 4: the last Linear of the classification heads,
+//      model/robotnet_segmentation.py:43-48).  1.5 flop per byte: an HBM stream, not a matrix problem - on the MFMA
+//      tiles 13 of 16 output columns would be padding and the step chain (gather -> LDS -> barrier) is latency-bound.
+//      Here a workgroup streams ROWS (64) rows: [ROWS x 32 channels] stages are read coalesced (8 lanes per 128-byte row
+//      segment), double-buffered through LDS (row stride 33 words: conflict-free), and thread r walks row r with the
+//      same ascending-channel fmaf chain as everywhere else (weights are wave-uniform -> scalar loads).
+template <int C, int ROWS>
+__global__ __launch_bounds__(256) void linear_narrow_kernel(ConvParams p) {
+  constexpr int COLS = 32, SW = COLS + 1, LPT = ROWS / 32;  // LPT float4 loads per thread and stage
+  __shared__ float tile[2][ROWS * SW];
+  const int tid = threadIdx.x;
+  const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+  const int Cin = p.Cin;
+  const int lr = tid >> 3, lc = (tid & 7) * 4;  // load mapping: row lr + 32 i, channels lc .. lc + 3
+  float4 ra[LPT];
+  auto load = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+      const int64_t r = row0 + lr + 32 * i;
+      const int c = c0 + lc;
+      const bool ok = r < p.V_out && c < Cin;
+      const float4 v = *(const float4*)(p.in + (ok ? r * p.in_ld + c : 0));
+      ra[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store = [&](float* dst) {
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+      float* d = dst + (lr + 32 * i) * SW + lc;
+      d[0] = ra[i].x;
+      d[1] = ra[i].y;
+      d[2] = ra[i].z;
+      d[3] = ra[i].w;
+    }
+  };
+  float acc[C];
+#pragma unroll
+  for (int j = 0; j < C; ++j) acc[j] = 0.0f;
+  load(0);
+  store(tile[0]);
+  __syncthreads();
+  int buf = 0;
+  for (int c0 = 0; c0 < Cin; c0 += COLS) {
+    const bool more = c0 + COLS < Cin;
+    if (more) load(c0 + COLS);
+    if (tid < ROWS) {
+      const float* x = tile[buf] + tid * SW;
+      const float* w = p.W + (int64_t)c0 * p.Cout;
+      const int nc = min(COLS, Cin - c0);  // channels beyond Cin hold zeros, but their weights would be out of bounds
+#pragma unroll 8
+      for (int c = 0; c < nc; ++c) {
+        const float xv = x[c];
+#pragma unroll
+        for (int j = 0; j < C; ++j) acc[j] = __builtin_fmaf(xv, w[c * p.Cout + j], acc[j]);
+      }
+    }
+    if (more) store(tile[buf ^ 1]);
+    __syncthreads();
+    buf ^= 1;
+  }
+  const int64_t r = row0 + tid;
+  if (tid >= ROWS || r >= p.V_out) return;
+#pragma unroll
+  for (int j = 0; j < C; ++j) {
+    float v = acc[j];
+    if (p.scale)
+      v = __builtin_fmaf(v, p.scale[j], p.shift ? p.shift[j] : 0.0f);
+    else if (p.shift)
+      v = v + p.shift[j];
+    if (p.residual) v = v + p.residual[r * p.res_ld + j];
+    if (p.act == SV_ACT_RELU)
+      v = v > 0.f ? v : 0.f;
+    else if (p.act == SV_ACT_LEAKY_RELU)
+      v = v > 0.f ? v : v * p.slope;
+    p.out[r * p.out_ld + j] = v;
+  }
+}
+
+template <int ROWS>
+static int launch_linear_narrow_rows(const ConvParams& p, hipStream_t stream) {
+  dim3 grid((unsigned)((p.V_out + ROWS - 1) / ROWS));
+  switch (p.Cout) {
+    case 1: hipLaunchKernelGGL((linear_narrow_kernel<1, ROWS>), grid, dim3(256), 0, stream, p); break;
+    case 2: hipLaunchKernelGGL((linear_narrow_kernel<2, ROWS>), grid, dim3(256), 0, stream, p); break;
+    case 3: hipLaunchKernelGGL((linear_narrow_kernel<3, ROWS>), grid, dim3(256), 0, stream, p); break;
+    default: hipLaunchKernelGGL((linear_narrow_kernel<4, ROWS>), grid, dim3(256), 0, stream, p); break;
+  }
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+static int launch_linear_narrow(const ConvParams& p, hipStream_t stream) {
+  static const int rows_env = getenv("SV_NARROW_ROWS") ? atoi(getenv("SV_NARROW_ROWS")) : 0;  // experiments only
+  const int rows = rows_env ? rows_env : 64;  // 256 / 128 / 64 / 32 rows: 3.2 / 3.6 / 3.9 / 2.8 TB/s on 88k x 1024 -> 3
+  if (rows == 256) return launch_linear_narrow_rows<256>(p, stream);
+  if (rows == 128) return launch_linear_narrow_rows<128>(p, stream);
+  if (rows == 32) return launch_linear_narrow_rows<32>(p, stream);
+  return launch_linear_narrow_rows<64>(p, stream);
+}
+
 template <int TM_, int WAVES_N, int NT, int CPO = 0>
 static int launch_conv(const ConvParams& p, hipStream_t stream) {
   using Cfg = ConvCfg<TM_, WAVES_N, NT, CPO>;
@@ -673,5 +772,7 @@ extern "C" int sv_conv_fwd(const float* in, int64_t in_ld, int Cin, const float*
   p.ntiles = 0;
   p.ny = 0;
   p.trace = nullptr;
+  static const bool no_narrow = getenv("SV_CONV_NO_NARROW") != nullptr;  // experiments only
+  if (!has_plan && K == 1 && Cout <= 4 && p.vec_a && Cin >= 64 && !no_narrow) return launch_linear_narrow(p, stream);
   return select_and_launch(p, stream);
 }

@@ -31,6 +31,8 @@ _FUSED = {  # (Cin, Cout) -> candidates of the fused-offset form (thin layers, K
 def conv_kernel_config(Cout, Vpad, Cin=None, K=1):
     """Mirror of select_and_launch() in csrc/sv_conv.hip -> kernel instance name: conv_fwd_kernel<TM, WAVES_N, NT>,
     with ", fused Cin" appended for the fused-offset form of the thin layers."""
+    if K == 1 and Cout <= 4 and Cin is not None and Cin >= 64 and Cin % 4 == 0:
+        return f"linear_narrow_kernel<{Cout}>"  # dense rows only; every K = 1 layer of the path is dense
     fused = None
     if K > 1 and Cin is not None:
         if Cin == 3 and 16 < Cout <= 32:

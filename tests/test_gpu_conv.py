@@ -76,7 +76,7 @@ def test_conv_down_up_bit_exact(gpu, oracle, cin, cout):
 
 
 @pytest.mark.parametrize("V,cin,cout", [(1, 4, 4), (127, 256, 1024), (129, 1024, 3), (5000, 384, 256), (300, 9, 7),
-                                        (64, 2048, 7)])
+                                        (64, 2048, 7), (5000, 1024, 3), (777, 256, 2), (1000, 64, 4), (300, 100, 1)])
 def test_dense_linear_bit_exact(gpu, oracle, V, cin, cout):
     from mrcc_amd import nn as svnn
 
@@ -137,4 +137,25 @@ def test_conv_every_tile_shape_of_the_pyramid_bit_exact(gpu, oracle, level, cin)
     t = lambda a: torch.from_numpy(a).to(gpu)
     got = svnn.conv_forward(t(x), t(W), plan, V, t(scale), t(shift), None, 1).cpu().numpy()
     want = oracle.conv(x, W, frame.k3(ts), V, scale, shift, None, oracle.ACT_RELU)
+    assert _same(got, want), f"max abs diff {np.abs(got - want).max()}"
+
+
+@pytest.mark.parametrize("cout", [1, 3, 4])
+def test_narrow_output_stream_kernel_epilogue(gpu, oracle, cout):
+    """The narrow-output dense layer (Cout <= 4) runs on the row-streaming kernel: same chain, same epilogue
+    (folded BN, residual, ReLU) and a strided input view."""
+    from mrcc_amd import nn as svnn
+
+    V, cin = 1300, 200
+    rng = np.random.default_rng(cout)
+    xfull = rng.normal(size=(V, cin + 56)).astype(np.float32)
+    x = xfull[:, :cin]
+    W = (rng.normal(size=(1, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, size=cout).astype(np.float32)
+    shift = rng.normal(size=cout).astype(np.float32)
+    res = rng.normal(size=(V, cout)).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(gpu)
+    xd = t(xfull)[:, :cin]  # row stride 256 floats, 200 used
+    got = svnn.conv_forward(xd, t(W), None, V, t(scale), t(shift), t(res), 1).cpu().numpy()
+    want = oracle.conv(np.ascontiguousarray(x), W, None, V, scale, shift, res, oracle.ACT_RELU)
     assert _same(got, want), f"max abs diff {np.abs(got - want).max()}"
