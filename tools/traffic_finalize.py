@@ -13,6 +13,9 @@ raw = json.load(open(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "g
 
 
 def fold(name):
+    m = re.search(r"linear_narrow_kernel<(\d+)", name)
+    if m:
+        return f"linear_narrow_kernel<{m.group(1)}>"
     m = re.search(r"conv_fwd_kernel<([^>]*)>", name)
     a = [x.strip() for x in m.group(1).split(",")]
     cpo = int(a[4]) if len(a) > 4 else 0
