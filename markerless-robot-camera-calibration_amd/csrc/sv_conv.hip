@@ -576,6 +576,88 @@ __global__ __launch_bounds__(256) void linear_narrow_kernel(ConvParams p) {
   }
 }
 
+// ---- first layer of the networks (conv0: Cin = 3 colour channels -> 32, 3x3x3, every voxel of the frame;
+//      model/backbone/minkunet.py:55-57).  5.8 flop per byte of gather traffic: the layer is its gather.  One THREAD
+//      per output voxel (in the plan's mask-sorted order, so a wavefront's rows share most neighbour offsets and an
+//      offset nobody has is skipped for the whole wave): neighbour indices are read coalesced from the plan, the
+//      3-float input rows come from the (cache-resident, 1 MB) feature table, the 27 x 3 x 32 weights are wave-uniform
+//      scalar loads (SGPR operands of the fma), and the 32 accumulators per voxel are plain VALU fmaf chains in the same
+//      (offset ascending, channel ascending) order as the matrix path.
+template <int CIN, int COUT, int SPLIT>
+__global__ __launch_bounds__(256) void conv_first_layer_kernel(ConvParams p) {
+  constexpr int CT = COUT / SPLIT;  // output channels per thread; blockIdx.y selects the slice
+  constexpr int KMAX = 27;
+  const int tid = threadIdx.x;
+  const int K = p.K;
+  const int j0 = (int)blockIdx.y * CT;
+  const float* __restrict__ w_s = p.W + j0;  // wave-uniform indices below -> scalar loads, weights as SGPR operands
+  const int64_t r = (int64_t)blockIdx.x * 256 + tid;  // plan position
+  const bool in_range = r < p.Vpad;
+  const int64_t o = in_range ? (int64_t)p.perm[r] : -1;
+  float acc[CT];
+#pragma unroll
+  for (int j = 0; j < CT; ++j) acc[j] = 0.0f;
+  int n[KMAX];  // all neighbour indices of the voxel are requested up front (coalesced across the wavefront)
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) n[k] = (o >= 0 && k < K) ? p.nbr_s[(int64_t)k * p.Vpad + r] : -1;
+  constexpr int G = 9;  // input rows in flight per thread
+#pragma unroll
+  for (int k0 = 0; k0 < KMAX; k0 += G) {
+    float x[G][CIN];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float* src = p.in + (n[k0 + g] >= 0 ? (int64_t)n[k0 + g] * p.in_ld : 0);
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) x[g][c] = src[c];
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const bool has = n[k0 + g] >= 0;
+      if (__ballot(has) == 0ull) continue;  // no voxel of this wavefront has a neighbour at this offset
+      const float* w = w_s + (k0 + g) * CIN * COUT;
+      if (has) {
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) {
+#pragma unroll
+          for (int j = 0; j < CT; ++j) acc[j] = __builtin_fmaf(x[g][c], w[c * COUT + j], acc[j]);
+        }
+      }
+    }
+  }
+  if (o < 0) return;
+  float* dst = p.out + o * p.out_ld + j0;
+#pragma unroll
+  for (int j = 0; j < CT; ++j) {
+    float v = acc[j];
+    if (p.scale)
+      v = __builtin_fmaf(v, p.scale[j0 + j], p.shift ? p.shift[j0 + j] : 0.0f);
+    else if (p.shift)
+      v = v + p.shift[j0 + j];
+    if (p.residual) v = v + p.residual[o * p.res_ld + j0 + j];
+    if (p.act == SV_ACT_RELU)
+      v = v > 0.f ? v : 0.f;
+    else if (p.act == SV_ACT_LEAKY_RELU)
+      v = v > 0.f ? v : v * p.slope;
+    acc[j] = v;
+  }
+  if ((p.out_ld & 3) == 0 && (((uintptr_t)p.out) & 15) == 0) {
+#pragma unroll
+    for (int j = 0; j < CT; j += 4) *(float4*)(dst + j) = make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < CT; ++j) dst[j] = acc[j];
+  }
+}
+
+static int launch_conv_first_layer(const ConvParams& p, hipStream_t stream) {
+  // SPLIT = 1: one thread computes all 32 channels of its voxel (two / four threads per voxel measured 18 / 26 us
+  // against 16 us: the gathers are repeated per slice)
+  dim3 grid((unsigned)((p.Vpad + 255) / 256), 1);
+  hipLaunchKernelGGL((conv_first_layer_kernel<3, 32, 1>), grid, dim3(256), 0, stream, p);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
 template <int ROWS>
 static int launch_linear_narrow_rows(const ConvParams& p, hipStream_t stream) {
   dim3 grid((unsigned)((p.V_out + ROWS - 1) / ROWS));
@@ -772,6 +854,8 @@ extern "C" int sv_conv_fwd(const float* in, int64_t in_ld, int Cin, const float*
   p.ntiles = 0;
   p.ny = 0;
   p.trace = nullptr;
+  static const bool no_first = getenv("SV_CONV_NO_FIRST") != nullptr;  // experiments only
+  if (has_plan && K > 1 && K <= 27 && Cin == 3 && Cout == 32 && !no_first) return launch_conv_first_layer(p, stream);
   static const bool no_narrow = getenv("SV_CONV_NO_NARROW") != nullptr;  // experiments only
   if (!has_plan && K == 1 && Cout <= 4 && p.vec_a && Cin >= 64 && !no_narrow) return launch_linear_narrow(p, stream);
   return select_and_launch(p, stream);

@@ -33,6 +33,8 @@ def conv_kernel_config(Cout, Vpad, Cin=None, K=1):
     with ", fused Cin" appended for the fused-offset form of the thin layers."""
     if K == 1 and Cout <= 4 and Cin is not None and Cin >= 64 and Cin % 4 == 0:
         return f"linear_narrow_kernel<{Cout}>"  # dense rows only; every K = 1 layer of the path is dense
+    if K > 1 and Cin == 3 and Cout == 32:
+        return "conv_first_layer_kernel<3, 32>"
     fused = None
     if K > 1 and Cin is not None:
         if Cin == 3 and 16 < Cout <= 32:
