@@ -78,6 +78,8 @@ def run_frames(model, pipe, frames, steps, hist=None):
     cls = torch.arange(3, device=frames[0][1].device).unsqueeze(1)
 
     def unet(x, field):
+        if profiling.TIMER is not None:
+            profiling.TIMER.frame_boundary()
         out = model(x)
         label, conf = out.slice_argmax(field)
         if hist is not None:  # asynchronous label histogram on the frame's own stream

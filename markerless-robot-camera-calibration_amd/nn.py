@@ -44,8 +44,7 @@ def conv_forward(feats, weight3, plan, V_out, scale=None, shift=None, residual=N
     t0 = None
     if timer is not None:
         kname = profiling.conv_kernel_config(Cout, Vpad, Cin, K)
-        # the first conv of a frame (Cin = 3) follows a cross-stream wait: its event interval absorbs the idle gap
-        if Cin >= 8 and timer.want(kname):
+        if timer.want(kname):
             t0 = timer.start()
     call("sv_conv_fwd", ptr(feats), c_int64(feats.stride(0)), c_int(Cin), ptr(weight3), c_int(K), c_int(Cout),
          ptr(perm), ptr(nbr_s), ptr(submask), ptr(tile_order), c_int64(V_out), c_int64(Vpad), ptr(scale), ptr(shift),

@@ -70,6 +70,7 @@ class KernelTimer:
         # events are created up front: creating ~250 of them per frame inside the timed region costs milliseconds
         self._pool = [torch.cuda.Event(enable_timing=True) for _ in range(capacity)]
         self._next = 0
+        self._first_of_frame = False
 
     def _event(self):
         if self._next < len(self._pool):
@@ -89,7 +90,13 @@ class KernelTimer:
     def stop(self, start_evt, kernel, K, Cin, Cout, V_out, pairs_dev):
         e = self._event()
         e.record()
-        self.records.append((kernel, K, Cin, Cout, V_out, pairs_dev, start_evt, e))
+        self.records.append((kernel, K, Cin, Cout, V_out, pairs_dev, start_evt, e, self._first_of_frame))
+        self._first_of_frame = False
+
+    def frame_boundary(self):
+        """The next timed launch is the first of a frame: its event interval can absorb the wait for the prepared
+        frame (cross-stream) or for the host, so summarize() leaves it out."""
+        self._first_of_frame = True
 
     def clear(self):
         self.records = []
@@ -98,7 +105,9 @@ class KernelTimer:
         """After torch.cuda.synchronize(): per-kernel {launches, ms, flops, gather_bytes} (SURVEY.md §8d formulas:
         flops = 2 P Cin Cout; gather-bytes = P (4 Cin + 8) + 4 N_out Cout + 4 K Cin Cout)."""
         out = {}
-        for kernel, K, Cin, Cout, V_out, pairs_dev, s, e in self.records:
+        for kernel, K, Cin, Cout, V_out, pairs_dev, s, e, first in self.records:
+            if first:
+                continue
             P = int(pairs_dev.item()) if pairs_dev is not None else V_out
             ms = s.elapsed_time(e)
             d = out.setdefault(kernel, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})

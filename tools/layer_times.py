@@ -31,7 +31,7 @@ with torch.no_grad():
         pipe.run(cur, unet)
         torch.cuda.synchronize()
         profiling.TIMER = None
-        for idx, (kernel, K, Cin, Cout, V, pairs, s, e) in enumerate(t.records):
+        for idx, (kernel, K, Cin, Cout, V, pairs, s, e, _first) in enumerate(t.records):
             P = int(pairs.item()) if pairs is not None else V
             a = acc.setdefault(idx, [kernel, K, Cin, Cout, V, P, 0.0])
             a[6] += s.elapsed_time(e) / REP
