@@ -95,7 +95,7 @@ struct ConvCfg {
   // the FULL form (see the kernel) pays where a k-step is one or two matrix ops and the per-k-step bookkeeping of
   // the general form dominates; on the 64-row tile it costs the 129th VGPR (3 instead of 4 waves per SIMD) and on
   // 16x128 tiles it measured slower (profiles/r01_conv_full_form.txt)
-  static constexpr bool USE_FULL = (MR * NT == 1) || (TM_ == 32 && WAVES_N == 4 && NT == 3);
+  static constexpr bool USE_FULL = (MR * NT == 1) || (TM_ == 32 && WAVES_N == 4 && NT == 3) || (TM_ == 16 && NT == 3);
   static constexpr int F4_PER_ROW = KC / 4;      // float4 per gathered row and step
   static constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
   static constexpr int A_F4 = (TM_ + ROWS_PER_PASS - 1) / ROWS_PER_PASS;  // float4 gathers per thread and step
