@@ -76,8 +76,8 @@ class MinkUNetBase(ResNetBase):
         n = self.N_LEVELS
         for j in range(n, 2 * n):
             conv, bn, block = self._up_names(j)
-            out = getattr(self, conv).forward_fused(out, bn=getattr(self, bn), act=SV_ACT_RELU)
-            out = ME.cat(out, skips.pop())
+            # transposed conv + BN + ReLU written straight into the left columns of ME.cat(out, skip)
+            out = getattr(self, conv).forward_fused(out, bn=getattr(self, bn), act=SV_ACT_RELU, cat_with=skips.pop())
             out = getattr(self, block)(out)
         return out
 

@@ -153,7 +153,10 @@ class _ConvBase(nn.Module):
         raise NotImplementedError(
             f"kernel_size={ks} stride={st} transposed={self.transposed}: not used by the reference's U-Nets")
 
-    def forward_fused(self, x, bn=None, residual=None, act=SV_ACT_NONE, slope=0.01):
+    def forward_fused(self, x, bn=None, residual=None, act=SV_ACT_NONE, slope=0.01, cat_with=None):
+        """conv (+ folded BN / bias) (+ residual) (+ activation) in one launch.  cat_with: a SparseTensor on the
+        output's coordinate map - the result is ME.cat(conv(x), cat_with) (model/backbone/minkunet.py:152-156), with
+        the conv writing straight into the left columns of the concatenated buffer instead of being copied there."""
         plan, out_stride = self._plan(x)
         V_out = x.coordinate_manager.stride_map(out_stride).V
         scale = shift = None
@@ -164,8 +167,17 @@ class _ConvBase(nn.Module):
         elif self.bias is not None:
             shift = self.bias.detach().reshape(-1)
         res = residual.F if isinstance(residual, SparseTensor) else residual
-        out = conv_forward(x.F, self.weight3().detach(), plan, V_out, scale, shift, res, act, slope)
-        return x.new(out, tensor_stride=out_stride)
+        if cat_with is None:
+            out = conv_forward(x.F, self.weight3().detach(), plan, V_out, scale, shift, res, act, slope)
+            return x.new(out, tensor_stride=out_stride)
+        if cat_with.coordinate_manager is not x.coordinate_manager or cat_with.tensor_stride != out_stride:
+            raise ValueError("ME.cat needs tensors on the same coordinate map")
+        skip = cat_with.F
+        C = self.out_channels
+        buf = torch.empty((V_out, C + skip.shape[1]), dtype=torch.float32, device=x.F.device)
+        conv_forward(x.F, self.weight3().detach(), plan, V_out, scale, shift, res, act, slope, out=buf[:, :C])
+        buf[:, C:].copy_(skip)
+        return x.new(buf, tensor_stride=out_stride)
 
     def forward(self, x):
         return self.forward_fused(x)
