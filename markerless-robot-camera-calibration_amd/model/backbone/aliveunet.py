@@ -28,6 +28,13 @@ class AliveUNetBase(MinkUNetBase):
             return self.PLANES[13] + self.INIT_DIM
         return self.PLANES[j + 1] + self.PLANES[13 - j] * self.BLOCK.expansion
 
+    def _decoder_block(self, j):
+        # aliveunet.py:123,130,137,144,151,158: block(j+1) = _make_layer(BLOCK, PLANES[j+1], LAYERS[j+1]) for
+        # j = 7..12 — one table entry further than MinkUNet — and :165: block14 = (PLANES[13], LAYERS[13]).  The
+        # transposed conv after block(j+1) therefore maps PLANES[j+1]*expansion -> PLANES[j+1] (:124-126).
+        k = min(j + 1, 13)
+        return self.PLANES[k], self.LAYERS[k]
+
     def forward(self, x):
         return self.forward_except_final(x)
 

@@ -38,6 +38,10 @@ class MinkUNetBase(ResNetBase):
         # minkunet.py:91,98,105,112: width after ME.cat(convtr_j output, encoder skip)
         return self.PLANES[j] + skip_planes[2 * self.N_LEVELS - 1 - j]
 
+    def _decoder_block(self, j):
+        # minkunet.py:92,99,106,113: block(j+1) = _make_layer(BLOCK, PLANES[j], LAYERS[j])
+        return self.PLANES[j], self.LAYERS[j]
+
     def network_initialization(self, in_channels, out_channels, D):
         n, P, L, exp = self.N_LEVELS, self.PLANES, self.LAYERS, self.BLOCK.expansion
         self.inplanes = self.INIT_DIM
@@ -56,7 +60,7 @@ class MinkUNetBase(ResNetBase):
                                                                  dimension=D))
             setattr(self, bn, ME.MinkowskiBatchNorm(P[j]))
             self.inplanes = self._decoder_inplanes(j, skip_planes)
-            setattr(self, block, self._make_layer(self.BLOCK, P[j], L[j]))
+            setattr(self, block, self._make_layer(self.BLOCK, *self._decoder_block(j)))
         self.final = ME.MinkowskiConvolution(P[2 * n - 1] * exp, out_channels, kernel_size=1, bias=True, dimension=D)
         self.relu = ME.MinkowskiReLU(inplace=True)
 

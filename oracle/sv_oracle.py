@@ -315,22 +315,41 @@ def basic_block(sd, prefix, x, frame, stride, has_downsample):
     return conv(out, _kernel3(sd, prefix + ".conv2.kernel"), nbr, V, s2, b2, res, ACT_RELU)
 
 
+def bottleneck_block(sd, prefix, x, frame, stride, has_downsample):
+    """ME Bottleneck (resnet_block, expansion 4): 1x1-BN-ReLU, 3x3x3-BN-ReLU, 1x1-BN, (+residual), ReLU; residual
+    path 1x1 conv + BN when the width changes (model/backbone/resnet.py:95-107 builds it the same way)."""
+    V = x.shape[0]
+    s1, b1 = _bn(sd, prefix + ".norm1")
+    out = conv(x, _kernel3(sd, prefix + ".conv1.kernel"), None, V, s1, b1, None, ACT_RELU)
+    s2, b2 = _bn(sd, prefix + ".norm2")
+    out = conv(out, _kernel3(sd, prefix + ".conv2.kernel"), frame.k3(stride), V, s2, b2, None, ACT_RELU)
+    if has_downsample:
+        sd_, bd_ = _bn(sd, prefix + ".downsample.1")
+        res = conv(x, _kernel3(sd, prefix + ".downsample.0.kernel"), None, V, sd_, bd_)
+    else:
+        res = x
+    s3, b3 = _bn(sd, prefix + ".norm3")
+    return conv(out, _kernel3(sd, prefix + ".conv3.kernel"), None, V, s3, b3, res, ACT_RELU)
+
+
 def _block_stack(sd, name, x, frame, stride):
     i = 0
     while f"{name}.{i}.conv1.kernel" in sd:
-        x = basic_block(sd, f"{name}.{i}", x, frame, stride, f"{name}.{i}.downsample.0.kernel" in sd)
+        block = bottleneck_block if f"{name}.{i}.conv3.kernel" in sd else basic_block
+        x = block(sd, f"{name}.{i}", x, frame, stride, f"{name}.{i}.downsample.0.kernel" in sd)
         i += 1
     return x
 
 
-def minkunet_encoder(sd, feats, frame):
-    """model/backbone/minkunet.py:126-148 — conv0(k3)+BN+ReLU, then 4 x [conv k2 s2 + BN + ReLU, block]."""
+def minkunet_encoder(sd, feats, frame, levels=4):
+    """model/backbone/minkunet.py:126-148 — conv0(k3)+BN+ReLU, then 4 x [conv k2 s2 + BN + ReLU, block]
+    (model/backbone/aliveunet.py:178-216: the same with 7 stages)."""
     V0 = feats.shape[0]
     s, b = _bn(sd, "bn0")
     out_p1 = conv(feats, _kernel3(sd, "conv0p1s1.kernel"), frame.k3(1), V0, s, b, None, ACT_RELU)
     skips = [out_p1]
     out = out_p1
-    for i in range(1, 5):
+    for i in range(1, levels + 1):
         ts = 2 ** (i - 1)
         coarse = frame.down(ts)
         s, b = _bn(sd, f"bn{i}")
@@ -350,6 +369,22 @@ def minkunet_forward_except_final(sd, feats, frame):
         fine = frame.maps[ts // 2]
         out = conv(out, _kernel3(sd, f"convtr{j}p{ts}s2.kernel"), frame.kup(ts), len(fine), s, b, None, ACT_RELU)
         out = np.concatenate([out, skips.pop()], axis=1)  # ME.cat
+        out = _block_stack(sd, f"block{j + 1}", out, frame, ts // 2)
+    return out
+
+
+def alive_unet_forward(sd, feats, frame):
+    """model/backbone/aliveunet.py:177-265: 7 stages down to tensor stride 128, then convtr{j} + BN + ReLU,
+    ME.cat with the encoder tensor of that stride, block{j+1} for j = 7..13; returns block14's output (`final` is
+    constructed but never applied, :264-265)."""
+    skips = minkunet_encoder(sd, feats, frame, levels=7)
+    out = skips.pop()
+    for j in range(7, 14):
+        ts = 2 ** (14 - j)
+        s, b = _bn(sd, f"bntr{j}")
+        fine = frame.maps[ts // 2]
+        out = conv(out, _kernel3(sd, f"convtr{j}.kernel"), frame.kup(ts), len(fine), s, b, None, ACT_RELU)
+        out = np.concatenate([out, skips.pop()], axis=1)  # ME.cat(out, out_b{.}p{ts/2})
         out = _block_stack(sd, f"block{j + 1}", out, frame, ts // 2)
     return out
 
@@ -383,9 +418,11 @@ def _pose_mlp(sd, pooled, training=False):
     return out
 
 
-def robotnet_forward(sd, feats, frame):
-    """model/robotnet.py:62-83: forward_except_final -> BN+ReLU -> global max pool -> MLP -> normalise quaternion."""
-    out = minkunet_forward_except_final(sd, feats, frame)
+def robotnet_forward(sd, feats, frame, backbone=None):
+    """model/robotnet.py:62-83: forward_except_final -> BN+ReLU -> global max pool -> MLP -> normalise quaternion.
+    backbone: the U-Net body (default MinkUNet's forward_except_final; alive_unet_forward for the fallback backbone,
+    model/robotnet.py:29-30)."""
+    out = (backbone or minkunet_forward_except_final)(sd, feats, frame)
     s, b = _bn(sd, "output_layer.0")
     out = affine_act(out, s, b, None, ACT_RELU)
     pooled = global_pool(out, frame.maps[1], POOL_MAX)

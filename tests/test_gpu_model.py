@@ -104,3 +104,73 @@ def test_pose_heads_within_tolerance(gpu, oracle):
         assert np.allclose(np.linalg.norm(got[:, 3:7], axis=1), 1.0, atol=1e-5)
         # reference indexing of the result: rot_output[0][3:] (app/inference_engine.py:457)
         assert got[0][3:].shape == (4,)
+
+
+def _oracle_inputs(oracle, rgb, coords4):
+    vox = oracle.voxelize(coords4)
+    return vox, oracle.voxel_reduce(rgb, vox["order"], vox["seg_start"], 0)
+
+
+def test_alive_unet_bit_exact_and_pose_head(gpu, oracle):
+    """A4: the 7-level fallback backbone with the reference's default STRUCTURE (m = 32, block_reps = 2,
+    config/default.yaml:69-70) against the oracle's restatement of model/backbone/aliveunet.py:177-265, and the
+    RobotNet head on top of it (model/robotnet.py:29-30 picks AliveUNet for every non-minkunet backbone name)."""
+    from mrcc_amd import MinkowskiEngine as ME
+    from mrcc_amd.model.backbone.aliveunet import make_alive_unet
+    from mrcc_amd.model.robotnet import make_robotnet
+
+    pts, rgb, lab, coords4 = _cloud(9000, 1.5, 11, 100)  # 150 voxels across: the stride-128 level has several voxels
+    vox, feats = _oracle_inputs(oracle, rgb, coords4)
+    torch.manual_seed(3)
+    net = make_alive_unet(m=32, block_reps=2, bottleneck=False)(3, 8)
+    _randomize_bn(net, 4)
+    net = net.to(gpu).eval()
+    sd = {k: v.cpu() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        x = ME.TensorField(torch.from_numpy(rgb), torch.from_numpy(coords4), device=gpu).sparse()
+        out = net(x)
+        assert sorted(x.coordinate_manager.maps) == [1, 2, 4, 8, 16, 32, 64, 128]
+    frame = oracle.Frame(vox["coords"])
+    want = oracle.alive_unet_forward(sd, feats, frame)
+    assert len(frame.maps[128]) > 1
+    got = out.F.cpu().numpy()
+    assert got.shape == want.shape == (len(vox["keys"]), 32)
+    assert np.array_equal(got, want), f"max diff {np.abs(got - want).max()}"
+    # pose head on the AliveUNet body
+    from mrcc_amd.utils.config import Config
+
+    Config.reset()
+    Config().update({"STRUCTURE": {"bottleneck": False}})  # default.yaml:76 says true, which the reference's own
+    torch.manual_seed(5)                                     # AliveUNet cannot run (declared 1088 vs concatenated 992)
+    head = make_robotnet(backbone="aliveunet")(3, 7)
+    Config.reset()
+    assert head.convtr8.kernel.shape == (8, 192, 192)
+    _randomize_bn(head, 6)
+    head = head.to(gpu).eval()
+    sdh = {k: v.cpu() for k, v in head.state_dict().items()}
+    with torch.no_grad():
+        got = head(ME.TensorField(torch.from_numpy(rgb), torch.from_numpy(coords4), device=gpu).sparse()).cpu().numpy()
+    want = oracle.robotnet_forward(sdh, feats, oracle.Frame(vox["coords"]), backbone=oracle.alive_unet_forward)
+    assert got.shape == (1, 7) and np.allclose(got, want, atol=1e-4, rtol=0), np.abs(got - want).max()
+
+
+@pytest.mark.parametrize("name", ["MinkUNet50", "MinkUNet101"])
+def test_bottleneck_backbones_bit_exact(gpu, oracle, name):
+    """A3: the Bottleneck (expansion 4) U-Nets of the heads' backbone tables (model/robotnet_segmentation.py:20-27,
+    model/backbone/minkunet.py:204-211) against the oracle's bottleneck_block restatement."""
+    from mrcc_amd import MinkowskiEngine as ME
+    from mrcc_amd.model.backbone import minkunet
+
+    pts, rgb, lab, coords4 = _cloud(5000, 0.5, 13, 50)
+    vox, feats = _oracle_inputs(oracle, rgb, coords4)
+    torch.manual_seed(7)
+    net = getattr(minkunet, name)(3, 16)
+    _randomize_bn(net, 8)
+    net = net.to(gpu).eval()
+    sd = {k: v.cpu() for k, v in net.state_dict().items()}
+    assert "block4.5.conv3.kernel" in sd and sd["block5.0.conv1.kernel"].shape == (256 + 128 * 4, 256)
+    with torch.no_grad():
+        out = net(ME.TensorField(torch.from_numpy(rgb), torch.from_numpy(coords4), device=gpu).sparse())
+    want = oracle.minkunet_forward(sd, feats, oracle.Frame(vox["coords"]))
+    got = out.F.cpu().numpy()
+    assert got.shape == want.shape and np.array_equal(got, want), f"max diff {np.abs(got - want).max()}"

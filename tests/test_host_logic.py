@@ -46,7 +46,44 @@ def test_heads_and_backbones_construct():
     assert b.final.kernel.shape == (96 * 4, 8)
     alive = make_alive_unet(m=16, block_reps=1, bottleneck=False)(3, 8)
     assert hasattr(alive, "conv7p64s2") and hasattr(alive, "convtr13") and hasattr(alive, "block14")
-    assert alive.block8[0].conv1.kernel.shape[1] == 16 * 7 + 16 * 6
+    assert alive.block8[0].conv1.kernel.shape == (27, 16 * 7 + 16 * 6, 16 * 6)
+
+
+# kernel shapes of AliveUNetBase with its default PLANES (32,64,96,128,160,192,224,224,192,160,128,96,64,32), LAYERS 1,
+# transcribed from /root/reference/model/backbone/aliveunet.py:62-174 (conv{i}: inplanes->inplanes :76-114; block{i} =
+# PLANES[i-1]; convtr7 -> PLANES[7] :116-119; inplanes = PLANES[j+1] + PLANES[13-j] :121,128,...; block{j+1} =
+# PLANES[j+1]; convtr{j+1}: inplanes -> PLANES[j+1]; block14 = PLANES[13] on PLANES[13] + INIT_DIM :163-165)
+ALIVE_KERNELS = {
+    "conv0p1s1": (27, 3, 32), "conv1p1s2": (8, 32, 32), "conv2p2s2": (8, 32, 32), "conv3p4s2": (8, 64, 64),
+    "conv4p8s2": (8, 96, 96), "conv5p16s2": (8, 128, 128), "conv6p32s2": (8, 160, 160), "conv7p64s2": (8, 192, 192),
+    "block1.0.conv1": (27, 32, 32), "block2.0.conv1": (27, 32, 64), "block3.0.conv1": (27, 64, 96),
+    "block4.0.conv1": (27, 96, 128), "block5.0.conv1": (27, 128, 160), "block6.0.conv1": (27, 160, 192),
+    "block7.0.conv1": (27, 192, 224),
+    "convtr7": (8, 224, 224), "block8.0.conv1": (27, 416, 192), "block8.0.downsample.0": (416, 192),
+    "convtr8": (8, 192, 192), "block9.0.conv1": (27, 352, 160), "block9.0.downsample.0": (352, 160),
+    "convtr9": (8, 160, 160), "block10.0.conv1": (27, 288, 128), "block10.0.downsample.0": (288, 128),
+    "convtr10": (8, 128, 128), "block11.0.conv1": (27, 224, 96), "block11.0.downsample.0": (224, 96),
+    "convtr11": (8, 96, 96), "block12.0.conv1": (27, 160, 64), "block12.0.downsample.0": (160, 64),
+    "convtr12": (8, 64, 64), "block13.0.conv1": (27, 96, 32), "block13.0.downsample.0": (96, 32),
+    "convtr13": (8, 32, 32), "block14.0.conv1": (27, 64, 32), "block14.0.conv2": (27, 32, 32),
+    "block14.0.downsample.0": (64, 32), "final": (32, 8),
+}
+
+
+def test_alive_unet_state_dict_matches_reference_table():
+    from mrcc_amd.model.backbone.aliveunet import AliveUNetBase, make_alive_unet
+
+    sd = AliveUNetBase(3, 8).state_dict()
+    for name, shape in ALIVE_KERNELS.items():
+        assert tuple(sd[name + ".kernel"].shape) == shape, name
+    assert sum(1 for k in sd if k.endswith(".kernel")) == 1 + 7 + 7 + 14 * 2 + 13 + 1  # 13 blocks change width
+    for j, c in zip(range(7, 14), (224, 192, 160, 128, 96, 64, 32)):
+        assert sd[f"bntr{j}.bn.weight"].shape == (c,)
+    # STRUCTURE.m / block_reps variant (aliveunet.py:268-275): planes m*(1..7,7..1), block_reps blocks per stage
+    sd = make_alive_unet(m=16, block_reps=2, bottleneck=False)(3, 8).state_dict()
+    assert tuple(sd["block8.0.conv1.kernel"].shape) == (27, 16 * 6 + 16 * 7, 16 * 6)
+    assert tuple(sd["convtr8.kernel"].shape) == (8, 96, 96) and tuple(sd["block8.1.conv2.kernel"].shape) == (27, 96, 96)
+    assert tuple(sd["block14.1.conv1.kernel"].shape) == (27, 16, 16)
 
 
 def test_config_override_and_backbone_selection():
