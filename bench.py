@@ -19,11 +19,46 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def _spawn_ranks_if_needed():
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed environment: start N fresh ranks (one process per
+    GPU) with torch.distributed.run and relay rank 0's JSON line.  This runs BEFORE torch / HIP are imported, so the
+    parent never touches the GPU and nothing is re-exec'ed; the parent exits with the children's return code."""
+    if __name__ != "__main__" or "WORLD_SIZE" in os.environ:
+        return
+    pre = argparse.ArgumentParser(add_help=False)
+    pre.add_argument("--gpus", type=int, default=1)
+    known, _ = pre.parse_known_args()
+    if known.gpus <= 1:
+        return
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, len(os.sched_getaffinity(0)) // known.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(known.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    sys.stdout.write(res.stdout)
+    sys.stdout.flush()
+    if res.returncode == 0 and not any(l.startswith("{") for l in res.stdout.splitlines()):
+        sys.stderr.write("bench.py launcher: the ranks exited 0 without printing the JSON line\n")
+        sys.exit(1)
+    sys.exit(res.returncode)
+
+
+_spawn_ranks_if_needed()
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
 # HIP multiplexes streams onto a few hardware queues (4 by default); the pipeline uses a prep stream plus two compute
 # streams besides torch's default one, and two compute streams sharing a queue would serialise.  Must be set before HIP
 # initialises.
@@ -102,32 +137,170 @@ def run_frames(model, pipe, frames, steps, hist=None):
     return voxels
 
 
-def cpu_baseline(model, budget_s=25.0):
-    """Time the oracle (C restatement, OpenMP over output rows) on the host cores.  Bounded: a quarter-size frame
-    first; the full 200k-point frame only if the estimate says it fits the budget."""
+def oracle_pass(model, budget_s=25.0):
+    """Run the oracle (C restatement, OpenMP over output rows) on the host cores, timed: a quarter-size frame first,
+    the full 200k-point seed-0 frame only if the estimate says it fits the budget.  Returns (cpu_baseline record,
+    checked frame = dict(pts, rgb, lab, ref) of the LARGEST frame the oracle labelled)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import sv_oracle as O
 
     cores = len(os.sched_getaffinity(0))
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     sd = {k: v.cpu() for k, v in model.state_dict().items()}
-    pts, rgb, _ = mrcc_amd.synth.gen_room(POINTS // 4, ROOM / 2, 0)
+    pts, rgb, lab = mrcc_amd.synth.gen_room(POINTS // 4, ROOM / 2, 0)
     t0 = time.perf_counter()
     r = O.predict_segmentation(sd, pts, rgb, SCALE)
     t_small = time.perf_counter() - t0
     v_small = len(r["vox"]["keys"])
+    checked = dict(pts=pts, rgb=rgb, lab=lab, ref=r, what=f"quarter-size frame ({POINTS // 4} pts, {v_small} voxels)")
+    note = ("scalar order-preserving fmaf chain per output row (the bit-exact oracle, AVX2 across output channels, "
+            "OpenMP over rows) - NOT a BLAS gather-GEMM; see cpu_baseline_gather_gemm for that")
     est_full = t_small * 4.0
+    # second CPU baseline, as SURVEY.md 8(d) describes the reference's CPU path: per kernel offset gather rows,
+    # torch.mm (MKL/OpenBLAS sgemm on all cores), scatter-add - on the quarter frame
+    torch.set_num_threads(cores)
+    t0 = time.perf_counter()
+    with _gather_gemm_conv(O):
+        r_mm = O.predict_segmentation(sd, pts, rgb, SCALE)
+    t_mm = time.perf_counter() - t0
+    mm = {"value": 1.0 / (4.0 * t_mm), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+          "sample": f"quarter-size frame ({POINTS // 4} pts, L={ROOM / 2} m, {v_small} voxels) took {t_mm:.2f} s; "
+                    f"value = 1 / (4 x that)",
+          "note": "same graph with every conv as gather -> torch.mm -> scatter-add per kernel offset (what "
+                  "MinkowskiEngine's CPU path does); sgemm reassociates sums, so labels agree with the chain oracle "
+                  f"on {float((r_mm['label'] == r['label']).mean()):.6f} of the points, not bit-exactly"}
     if est_full <= budget_s:
-        pts, rgb, _ = mrcc_amd.synth.gen_room(POINTS, ROOM, 0)
+        pts, rgb, lab = mrcc_amd.synth.gen_room(POINTS, ROOM, 0)
         t0 = time.perf_counter()
         r = O.predict_segmentation(sd, pts, rgb, SCALE)
         t_full = time.perf_counter() - t0
-        return {"value": 1.0 / t_full, "unit": "frames/s", "cores": O.lib().or_num_threads(), "kind": "port",
+        checked = dict(pts=pts, rgb=rgb, lab=lab, ref=r, what=f"full frame ({POINTS} pts, seed 0)")
+        base = {"value": 1.0 / t_full, "unit": "frames/s", "cores": O.lib().or_num_threads(), "kind": "port",
                 "sample": f"1 full frame: {POINTS} pts, {len(r['vox']['keys'])} voxels, {t_full:.2f} s "
-                          f"(C oracle, OpenMP, fp32 fmaf chain; quarter frame took {t_small:.2f} s)"}
-    return {"value": 1.0 / est_full, "unit": "frames/s", "cores": O.lib().or_num_threads(), "kind": "port",
-            "sample": f"quarter-size frame ({POINTS // 4} pts, L={ROOM / 2} m, {v_small} voxels) took {t_small:.2f} s; "
-                      f"value = 1 / (4 x that): work is linear in voxels"}
+                          f"(C oracle, OpenMP, fp32 fmaf chain; quarter frame took {t_small:.2f} s)", "note": note}
+    else:
+        base = {"value": 1.0 / est_full, "unit": "frames/s", "cores": O.lib().or_num_threads(), "kind": "port",
+                "sample": f"quarter-size frame ({POINTS // 4} pts, L={ROOM / 2} m, {v_small} voxels) took "
+                          f"{t_small:.2f} s; value = 1 / (4 x that): work is linear in voxels", "note": note}
+    return base, mm, checked
+
+
+class _gather_gemm_conv:
+    """Context manager: swap the oracle's conv for a gather -> torch.mm -> scatter-add formulation (timing only)."""
+
+    def __init__(self, O):
+        self.O = O
+
+    def __enter__(self):
+        O = self.O
+        self.orig = O.conv
+
+        def conv_mm(feats, W, nbr, V_out, scale=None, shift=None, residual=None, act=O.ACT_NONE, slope=0.01,
+                    nthreads=None):
+            x = torch.from_numpy(np.ascontiguousarray(feats, dtype=np.float32))
+            Wt = torch.from_numpy(np.ascontiguousarray(W if W.ndim == 3 else W[None], dtype=np.float32))
+            K, Cin, Cout = Wt.shape
+            if nbr is None:
+                acc = x @ Wt[0]
+            else:
+                acc = torch.zeros((V_out, Cout), dtype=torch.float32)
+                nb = torch.from_numpy(np.ascontiguousarray(nbr)).long()
+                for k in range(K):
+                    rows = torch.nonzero(nb[k] >= 0).squeeze(1)
+                    if rows.numel():
+                        acc.index_add_(0, rows, x[nb[k][rows]] @ Wt[k])
+            if scale is not None:
+                acc = acc * torch.from_numpy(np.asarray(scale, np.float32)) + torch.from_numpy(
+                    np.asarray(shift, np.float32).reshape(-1))
+            elif shift is not None:
+                acc = acc + torch.from_numpy(np.asarray(shift, np.float32).reshape(-1))
+            if residual is not None:
+                acc = acc + torch.from_numpy(np.ascontiguousarray(residual, dtype=np.float32))
+            if act == O.ACT_RELU:
+                acc = torch.relu(acc)
+            elif act == O.ACT_LEAKY:
+                acc = torch.nn.functional.leaky_relu(acc, slope)
+            return acc.numpy()
+
+        O.conv = conv_mm
+        return self
+
+    def __exit__(self, *exc):
+        self.O.conv = self.orig
+
+
+def accuracy_block(model, device, checked):
+    """The "seg mIoU + pose ADD vs ref" half of the metric (SURVEY.md 8(d) parity gates): the GPU path and the oracle on
+    the SAME frame and weights - labels equal, mIoU(GPU vs oracle labels), mIoU / reference accuracy against the
+    synthetic ground truth for both (random-init weights: the absolute numbers only say both sides agree) - and 64
+    Kabsch problems: ADD between the GPU pose and the oracle pose over the end-effector points (utils/metrics.py:139-150)."""
+    import sv_oracle as O
+    from mrcc_amd.utils import metrics as M
+    from mrcc_amd.utils import transformation as T
+
+    pts, rgb, lab, ref = checked["pts"], checked["rgb"], checked["lab"], checked["ref"]
+    coords4 = np.concatenate([np.zeros((len(pts), 1), np.float32), pts * np.float32(SCALE)], axis=1)
+    with torch.no_grad():
+        field = ME.TensorField(torch.from_numpy(rgb), torch.from_numpy(coords4),
+                               quantization_mode=ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE, device=device)
+        x = field.sparse()
+        out = model(x)
+        label, _ = out.slice_argmax(field)
+    keys_equal = np.array_equal(x.coordinate_map.keys.cpu().numpy().view(np.uint64), ref["vox"]["keys"])
+    g = label.cpu().numpy()
+    o = ref["label"]
+    logits = out.F.cpu().numpy()
+    m_go = M.segmentation_metrics_from_confusion(M.confusion_matrix(g, o, 3))
+    m_g = M.segmentation_metrics_from_confusion(M.confusion_matrix(g, lab, 3))
+    m_o = M.segmentation_metrics_from_confusion(M.confusion_matrix(o, lab, 3))
+    B = 64
+    crops = [mrcc_amd.synth.gen_ee_crop(s, n=512) for s in range(B)]
+    kp_ref = np.repeat(mrcc_amd.synth.REFERENCE_KEY_POINTS[None], B, axis=0)
+    kp_tgt = np.stack([c[3] for c in crops])
+    R, t, q = T.get_rigid_transform_3D_batched(kp_ref, kp_tgt, device=device)
+    add_go, add_gt, dR = [], [], 0.0
+    for b in range(B):
+        Ro, to = O.get_rigid_transform_3D(kp_ref[b], kp_tgt[b])
+        qo = O.get_q_from_matrix(Ro)
+        qg = q[b] if np.dot(q[b], qo) >= 0 else -q[b]
+        local = (crops[b][0].astype(np.float64) - crops[b][2][:3]) @ mrcc_amd.synth.quat_to_matrix(crops[b][2][3:])
+        add_go.append(O.compute_ADD_np(local, np.concatenate([to, qo]), np.concatenate([t[b], qg])))
+        add_gt.append(O.compute_ADD_np(local, crops[b][2], np.concatenate([t[b], qg])))
+        dR = max(dR, float(np.abs(R[b] - Ro).max()))
+    return {
+        "frame": checked["what"], "voxels": int(logits.shape[0]),
+        "voxel_keys_equal": bool(keys_equal),
+        "logits_bit_exact": bool(np.array_equal(logits, ref["logits"])),
+        "labels_equal": bool(np.array_equal(g, o)),
+        "miou_gpu_vs_oracle": float(m_go["miou"]),
+        "miou_vs_gt_gpu": float(m_g["miou"]), "miou_vs_gt_oracle": float(m_o["miou"]),
+        "accuracy_vs_gt_gpu": float(m_g["accuracy"]), "accuracy_vs_gt_oracle": float(m_o["accuracy"]),
+        "kabsch_problems": B, "add_gpu_vs_oracle_max_m": float(max(add_go)),
+        "add_vs_gt_pose_mean_m": float(np.mean(add_gt)), "kabsch_max_abs_dR": dR,
+        "note": "weights are random-init (no checkpoints ship), so mIoU/accuracy against the synthetic ground truth are "
+                "chance-level by construction; the parity gates are labels_equal / miou_gpu_vs_oracle = 1.0 and "
+                "add_gpu_vs_oracle <= 1e-4 m",
+    }
+
+
+def launcher_selftest(args, world, rank):
+    """What the N-rank launch does around the GPU work, on the CPU: init (gloo), rank r takes frames r, r + world, ...,
+    ONE all_gather of the metrics record, max-over-ranks time, rank 0 prints the line."""
+    import torch.distributed as dist
+    from mrcc_amd.app.sharding import frame_seeds_for_rank, gather_metrics
+
+    if world > 1:
+        dist.init_process_group("gloo")
+    seeds = frame_seeds_for_rank(args.steps * world, rank, world)
+    agg = gather_metrics({"frames": len(seeds), "elapsed": 0.001 * (rank + 1), "confusion": np.eye(3, dtype=np.int64),
+                          "seed_sum": int(sum(seeds))}, device="cpu")
+    if rank == 0:
+        print(json.dumps({"metric": "launcher selftest (no GPU work)", "n_gpus": world, "steps": args.steps,
+                          "frames": agg["frames"], "per_rank_frames": agg["per_rank_frames"],
+                          "seed_sum": agg["seed_sum"], "elapsed_max": agg["elapsed_max"], "selftest": True}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -141,12 +314,21 @@ def main():
     ap.add_argument("--streams", type=int, default=2, help="compute streams alternating between frames (1 = single)")
     ap.add_argument("--frames-per-step", type=int, default=1,
                     help="frames fused into one sparse tensor per step (batch column); 1 = the headline workload")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="CPU rehearsal of the N-rank launch: rendezvous (gloo), frame sharding, the one all_gather and "
+                         "the JSON line, without touching a GPU (tests/test_dist_cpu.py)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the torch.distributed environment has WORLD_SIZE={world}; "
+                         "launch with --nproc-per-node equal to --gpus (or run `python bench.py --gpus N`, which starts "
+                         "the ranks itself)")
     backend = os.environ.get("MRCC_DIST_BACKEND", "nccl")  # "gloo" = rehearsal with several ranks on one GPU
+    if args.launcher_selftest:
+        return launcher_selftest(args, world, rank)
     dev_index = local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         import torch.distributed as dist
@@ -267,8 +449,14 @@ def main():
             "roofline": roofline,
             "kernels_warmup": kernels,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(model)
+        if not args.no_cpu_baseline:
+            # the oracle pass gives both the timed CPU baseline (reported at N = 1, as the contract says) and the
+            # reference labels of the accuracy half of the metric (every N; the other ranks wait at the final barrier)
+            base, base_mm, checked = oracle_pass(model)
+            line["accuracy"] = accuracy_block(model, device, checked)
+            if world == 1:
+                line["cpu_baseline"] = base
+                line["cpu_baseline_gather_gemm"] = base_mm
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

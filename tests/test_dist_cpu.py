@@ -49,3 +49,35 @@ def test_shard_rule_is_a_partition():
         allf = sorted(s for r in range(world) for s in frame_seeds_for_rank(512, r, world))
         assert allf == list(range(512))
         assert frame_seeds_for_rank(512, 0, world)[:2] == [0, world] if world > 1 else True
+
+
+def _run_bench(args, env_extra=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` (no torch.distributed environment) must start 2 ranks itself and relay rank 0's
+    line with n_gpus = 2 (--gpus was parsed and ignored).  CPU rehearsal of everything around the GPU work."""
+    import json
+
+    res = _run_bench(["--gpus", "2", "--steps", "6", "--launcher-selftest"])
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["per_rank_frames"] == [6, 6] and out["frames"] == 12
+    assert out["seed_sum"] == sum(range(12)) and abs(out["elapsed_max"] - 0.002) < 1e-9
+    # N = 1 needs no launcher
+    res = _run_bench(["--gpus", "1", "--steps", "3", "--launcher-selftest"])
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])["n_gpus"] == 1
+
+
+def test_bench_rejects_world_size_mismatch_and_failing_ranks():
+    # a torch.distributed environment that disagrees with --gpus is an error, not a silent 1-rank run
+    res = _run_bench(["--gpus", "4", "--launcher-selftest"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert res.returncode != 0 and "WORLD_SIZE=1" in res.stderr
+    # a rank that dies makes the launcher exit non-zero (no GPU here: the real bench fails loudly in every rank)
+    res = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"], timeout=600)
+    assert res.returncode != 0
