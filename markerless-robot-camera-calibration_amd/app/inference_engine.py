@@ -143,7 +143,7 @@ class InferenceEngine:
         with torch.no_grad():
             x = self._field(pts, ee_rgb, cfg.INFERENCE.ROTATION.scale).sparse()
             out = self._rotation_model(x)
-        return out[0][3:7].cpu().numpy()
+        return out[0][3:].cpu().numpy()  # quaternion (+ confidences when STRUCTURE.compute_confidence), :446-454
 
     def predict_translation(self, ee_raw_points, ee_rgb, q=None):
         cfg = self._config
@@ -236,7 +236,8 @@ class InferenceEngine:
             result.ee_pose = self.match_icp(ee_pts, result.ee_pose)
             result.key_points_pose = self.match_icp(ee_pts, result.key_points_pose)
         if data.ee2base_pose is not None:
-            result.base_pose = get_base2cam_pose(result.ee_pose, data.ee2base_pose)
+            if result.ee_pose is not None:  # the ICP step may have rejected the pose (:364-369)
+                result.base_pose = get_base2cam_pose(result.ee_pose, data.ee2base_pose)
             if result.key_points_pose is not None:
                 result.key_points_base_pose = get_base2cam_pose(result.key_points_pose, data.ee2base_pose)
         return result

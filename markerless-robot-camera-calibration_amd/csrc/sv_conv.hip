@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
       for (int n = 0; n < NT; ++n) {
         float v = y[n];
         if (p.act == SV_ACT_RELU)
-          v = v > 0.f ? v : 0.f;
+          v = v < 0.f ? 0.f : v;  // NaN stays NaN, as torch.relu
         else if (p.act == SV_ACT_LEAKY_RELU)
           v = v > 0.f ? v : v * p.slope;
         if (col0 + n < Cout) dst[n] = v;
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256) void linear_narrow_kernel(ConvParams p) {
       v = v + p.shift[j];
     if (p.residual) v = v + p.residual[r * p.res_ld + j];
     if (p.act == SV_ACT_RELU)
-      v = v > 0.f ? v : 0.f;
+      v = v < 0.f ? 0.f : v;  // NaN stays NaN, as torch.relu
     else if (p.act == SV_ACT_LEAKY_RELU)
       v = v > 0.f ? v : v * p.slope;
     p.out[r * p.out_ld + j] = v;
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(256) void conv_first_layer_kernel(ConvParams p) {
       v = v + p.shift[j0 + j];
     if (p.residual) v = v + p.residual[o * p.res_ld + j0 + j];
     if (p.act == SV_ACT_RELU)
-      v = v > 0.f ? v : 0.f;
+      v = v < 0.f ? 0.f : v;  // NaN stays NaN, as torch.relu
     else if (p.act == SV_ACT_LEAKY_RELU)
       v = v > 0.f ? v : v * p.slope;
     acc[j] = v;

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
     y = y + shift[c];
   if (residual) y = y + residual[v * res_ld + c];
   if (act == SV_ACT_RELU)
-    y = y > 0.f ? y : 0.f;
+    y = y < 0.f ? 0.f : y;  // NaN stays NaN, as torch.relu
   else if (act == SV_ACT_LEAKY_RELU)
     y = y > 0.f ? y : y * slope;
   out[v * out_ld + c] = y;

@@ -19,7 +19,11 @@ from . import _lib, profiling
 from ._lib import SV_ACT_LEAKY_RELU, SV_ACT_NONE, SV_ACT_RELU, call, ptr, stream_ptr
 from .sparse import SparseTensor
 
-KERNEL_OFFSET_PERMUTATION = None  # optional list[int] of length K applied to `kernel` rows at load time
+# Adapting a checkpoint written by a MinkowskiEngine build whose kernel-offset numbering differs from this build's
+# (include/sv_hip.h: k = (dx+1) + 3 (dy+1) + 9 (dz+1), x fastest; k = dx + 2 dy + 4 dz for kernel_size 2):
+# {kernel_volume: perm} with  this_build_kernel[k] = checkpoint_kernel[perm[k]].  Applied to every `kernel` of that
+# volume inside load_state_dict (_ConvBase._load_from_state_dict); None = checkpoints already use this numbering.
+KERNEL_OFFSET_PERMUTATION = None
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -136,6 +140,19 @@ class _ConvBase(nn.Module):
     def weight3(self):
         w = self.kernel
         return w if w.dim() == 3 else w.unsqueeze(0)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        key = prefix + "kernel"
+        perm_table = KERNEL_OFFSET_PERMUTATION
+        if perm_table is not None and key in state_dict and state_dict[key].dim() == 3:
+            perm = perm_table.get(state_dict[key].shape[0]) if isinstance(perm_table, dict) else perm_table
+            if perm is not None and len(perm) == state_dict[key].shape[0]:
+                if sorted(perm) != list(range(len(perm))):
+                    raise ValueError(f"KERNEL_OFFSET_PERMUTATION for kernel volume {len(perm)} is not a permutation")
+                state_dict[key] = state_dict[key][torch.as_tensor(list(perm), device=state_dict[key].device)]
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                      error_msgs)
 
     def _plan(self, x):
         cm, ts = x.coordinate_manager, x.tensor_stride

@@ -369,6 +369,24 @@ class SparseTensor:
                             tensor_stride=self.tensor_stride if tensor_stride is None else tensor_stride,
                             _internal=True)
 
+    def _same_map(self, other):
+        if not isinstance(other, SparseTensor):
+            return NotImplemented
+        if other.coordinate_manager is not self.coordinate_manager or other.tensor_stride != self.tensor_stride:
+            raise ValueError("sparse tensor arithmetic needs both operands on the same coordinate map")
+        return other
+
+    def __add__(self, other):
+        """ME.SparseTensor `+` on a shared coordinate map (the residual add of ME's resnet blocks: `out += residual`)."""
+        o = self._same_map(other)
+        return o if o is NotImplemented else self.new(self._F + o._F)
+
+    __iadd__ = __add__
+
+    def __sub__(self, other):
+        o = self._same_map(other)
+        return o if o is NotImplemented else self.new(self._F - o._F)
+
     def slice(self, field):
         """Voxel -> point broadcast: TensorField whose rows are this tensor's rows at field.inverse_mapping."""
         if self.tensor_stride != 1:

@@ -20,9 +20,21 @@ def get_key_point_predictions(logits, conf_th=0.999):
 
 
 def get_pred_center(out, coords, ee_r=0.03, q=None):
-    """mean of the 8 highest-vote points (utils/output.py:45-64, without the optional quaternion offset)."""
+    """mean of the 8 highest-vote points, optionally moved by (-ee_r, 0, 0) rotated by the quaternion q (w first)
+    (utils/output.py:45-64)."""
     sel = out[:, 1].sort(descending=True)[1][:8]
-    return np.asarray(coords)[sel.cpu().numpy()].mean(axis=0)
+    pred_center = coords[sel.cpu().numpy()].mean(axis=0)
+    if q is not None:
+        from .transformation import get_quaternion_rotation_matrix_torch
+
+        if not isinstance(q, torch.Tensor):
+            q = torch.tensor(q, dtype=torch.float32)
+        rot_mat = get_quaternion_rotation_matrix_torch(q.view(1, -1))[0]
+        offset_rotated = torch.matmul(rot_mat, torch.tensor([-ee_r, 0, 0]))
+        if isinstance(pred_center, np.ndarray):
+            offset_rotated = offset_rotated.cpu().numpy()
+        pred_center += offset_rotated
+    return pred_center
 
 
 class ClusterUtil:

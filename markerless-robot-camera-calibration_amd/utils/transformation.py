@@ -77,6 +77,16 @@ def get_quaternion_rotation_matrix(Q_init, switch_w=True):
     ])
 
 
+def get_quaternion_rotation_matrix_torch(quaternions):
+    """(..., 4) quaternions, real part first and not necessarily unit -> (..., 3, 3) (utils/transformation.py:104-131)."""
+    r, i, j, k = torch.unbind(quaternions, -1)
+    two_s = 2.0 / (quaternions * quaternions).sum(-1)
+    o = torch.stack((1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r),
+                     two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r),
+                     two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)), -1)
+    return o.reshape(quaternions.shape[:-1] + (3, 3))
+
+
 def get_transformation_matrix(pose, switch_w=False):
     pose = np.asarray(pose, dtype=np.float64)
     out = np.eye(4)

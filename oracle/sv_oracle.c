@@ -26,7 +26,7 @@
 #define ACT_LEAKY 2
 
 static inline float apply_act(float y, int act, float slope) {
-  if (act == ACT_RELU) return y > 0.f ? y : 0.f;
+  if (act == ACT_RELU) return y < 0.f ? 0.f : y; /* NaN propagates (torch.relu semantics) */
   if (act == ACT_LEAKY) return y > 0.f ? y : y * slope;
   return y;
 }

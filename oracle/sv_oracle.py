@@ -96,6 +96,36 @@ def voxelize(coords4, coords_are_int=False):
     return dict(keys=ukeys, coords=ucoords, inverse=inverse, order=order.astype(np.int32), seg_start=seg_start)
 
 
+def sparse_quantize(coordinates, features=None, labels=None, quantization_size=None, ignore_label=-100):
+    """ME.utils.sparse_quantize as called by data/alivev2.py:290-296 (**parity unpinned**: ME 0.5.4's
+    utils/quantization.py is not installable here; restated from its public contract): voxel = floor(coordinate /
+    quantization_size); one row per occupied voxel, represented by its FIRST point in input order; a voxel whose points
+    carry more than one distinct label gets ignore_label.  Row order = this build's canonical key order (ME's is
+    unspecified).  Returns (int32 coords [V, 3 or 4], features of the representatives, labels, index, inverse)."""
+    c = np.asarray(coordinates)
+    if quantization_size is not None:
+        c = np.floor(c.astype(np.float64) / quantization_size)
+    elif np.issubdtype(c.dtype, np.floating):
+        c = np.floor(c)
+    c = c.astype(np.int64)
+    c4 = c if c.shape[1] == 4 else np.concatenate([np.zeros((len(c), 1), np.int64), c], axis=1)
+    keys = make_keys(c4)
+    ukeys, first, inverse = np.unique(keys, return_index=True, return_inverse=True)  # first occurrence per key
+    out = [c[first].astype(np.int32)]
+    out.append(None if features is None else np.asarray(features)[first])
+    if labels is not None:
+        lab = np.asarray(labels).astype(np.int64)
+        lo = np.full(len(ukeys), np.iinfo(np.int64).max)
+        hi = np.full(len(ukeys), np.iinfo(np.int64).min)
+        np.minimum.at(lo, inverse, lab)
+        np.maximum.at(hi, inverse, lab)
+        out.append(np.where(lo == hi, lab[first], ignore_label).astype(np.asarray(labels).dtype))
+    else:
+        out.append(None)
+    out += [first.astype(np.int64), inverse.astype(np.int64)]
+    return tuple(out)
+
+
 def voxel_reduce(feats, order, seg_start, mode=0):
     feats = _f32(feats)
     V = len(seg_start) - 1

@@ -159,3 +159,25 @@ def test_narrow_output_stream_kernel_epilogue(gpu, oracle, cout):
     got = svnn.conv_forward(xd, t(W), None, V, t(scale), t(shift), t(res), 1).cpu().numpy()
     want = oracle.conv(np.ascontiguousarray(x), W, None, V, scale, shift, res, oracle.ACT_RELU)
     assert _same(got, want), f"max abs diff {np.abs(got - want).max()}"
+
+
+def test_relu_epilogue_propagates_nan_like_torch(gpu, oracle):
+    """torch.relu keeps NaN (the reference's MinkowskiReLU is torch.relu on the features); the fused epilogue, the
+    stand-alone affine/activation kernel and the oracle must not turn an upstream NaN into 0."""
+    from mrcc_amd import nn as svnn
+
+    ME, field, st, coords4 = _setup(gpu, n=3000, L=0.4)
+    frame = oracle.Frame(oracle.voxelize(coords4)["coords"])
+    V = st.F.shape[0]
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(V, 32)).astype(np.float32)
+    x[V // 2, 5] = np.nan
+    W = (rng.normal(size=(27, 32, 64)) * 0.1).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(gpu)
+    got = svnn.conv_forward(t(x), t(W), st.coordinate_manager.plan_k3(1), V, act=1).cpu().numpy()
+    want = oracle.conv(x, W, frame.k3(1), V, act=oracle.ACT_RELU)
+    assert np.isnan(want).any() and np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.array_equal(got[~np.isnan(want)], want[~np.isnan(want)])
+    y = svnn.affine_act(t(x), act=1).cpu().numpy()
+    assert np.array_equal(np.isnan(y), np.isnan(x)) and np.array_equal(y[~np.isnan(x)], np.maximum(x, 0)[~np.isnan(x)])
+    assert np.array_equal(np.isnan(torch.relu(torch.from_numpy(x)).numpy()), np.isnan(y))

@@ -151,3 +151,22 @@ def test_icp_matches_oracle_and_recovers_pose(gpu, oracle):
     assert match(None, pose0) is pose0
     pose = match(crop, np.concatenate([T0[:3, 3], oracle.get_q_from_matrix(T0[:3, :3])]))
     assert np.abs(pose[:3] - t).max() < 3e-3
+
+
+def test_calibration_chain_vs_reference_golden(gpu, golden):
+    """N2: get_base2cam_pose / transform_pose2pose / get_pose_from_matrix (utils/transformation.py:87-101, 225-266;
+    callers app/inference_engine.py:152-244) with the matrix -> quaternion step on the device, against vectors
+    produced by the reference's own functions.  1e-4 is the north_star pose tolerance; observed < 1e-9."""
+    from mrcc_amd.utils import transformation as T
+
+    def close(a, b):
+        q = min(np.abs(a[3:] - b[3:]).max(), np.abs(a[3:] + b[3:]).max())  # q and -q are the same rotation
+        return max(np.abs(a[:3] - b[:3]).max(), q)
+
+    g = golden("calib_chain")
+    worst = 0.0
+    for b in range(len(g["ee2cam"])):
+        worst = max(worst, close(T.get_base2cam_pose(g["ee2cam"][b], g["ee2robot"][b]), g["base2cam"][b]))
+        worst = max(worst, close(T.transform_pose2pose(g["ee2cam"][b], g["ee2robot"][b]), g["pose2pose"][b]))
+        worst = max(worst, close(T.get_pose_from_matrix(g["matrix"][b]), g["pose_from_matrix"][b]))
+    assert worst < 1e-9, worst

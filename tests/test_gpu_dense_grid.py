@@ -1,0 +1,146 @@
+"""An INDEPENDENT end-to-end check of the sparse semantics this build defines (the sparse oracle is parity-unpinned:
+MinkowskiEngine cannot be installed).
+
+A whole MinkUNet14A is evaluated as a DENSE-GRID float64 torch network - conv3d / conv3d(stride 2) /
+conv_transpose3d(stride 2) masked to the active voxel sets, BatchNorm(eval), ReLU, channel concatenation, residual adds,
+1x1 convs - on a 32^3 grid that contains negative coordinates, and compared with the GPU path's logits (1e-4).  The
+dense model shares NO code with oracle/sv_oracle.py or the HIP path: no hash, no kernel map, no stride map, no Morton
+order.  What it pins is composition: which voxel is whose neighbour, floor on negative coordinates in the stride-2 maps,
+the transposed convolution landing on the encoder's map, the order of ME.cat, skip wiring over four levels, batch
+separation.  The graph below is written from /root/reference/model/backbone/minkunet.py:125-187 and resnet.py:95-127.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+G, OFF = 32, 16  # grid size and the shift that makes coordinates in [-16, 16) non-negative (a multiple of 2^4, so that
+                 # floor(c / 2^l) * 2^l of the sparse side is plain integer division on the shifted dense side)
+
+
+def _dense_weights3(kernel, transposed=False):
+    """ME kernel [K, Cin, Cout], offset index x fastest -> torch conv3d weight on a [N, C, Z, Y, X] tensor."""
+    K, cin, cout = kernel.shape
+    k = round(K ** (1 / 3))
+    w = kernel.double().reshape(k, k, k, cin, cout)  # [z, y, x, ci, co]
+    return w.permute(3, 4, 0, 1, 2).contiguous() if transposed else w.permute(4, 3, 0, 1, 2).contiguous()
+
+
+class DenseNet:
+    def __init__(self, sd, masks):
+        self.sd, self.masks = {k: v.detach().cpu() for k, v in sd.items()}, masks
+
+    def bn(self, x, name):
+        g = lambda s: self.sd[f"{name}.bn.{s}"].double().view(1, -1, 1, 1, 1)
+        return (x - g("running_mean")) / torch.sqrt(g("running_var") + 1e-5) * g("weight") + g("bias")
+
+    def conv(self, x, name, level):  # 3x3x3 (or 1x1x1) stride-1 convolution on the level's active set
+        w = self.sd[name + ".kernel"]
+        if w.dim() == 2:
+            out = F.conv3d(x, w.double().t().reshape(w.shape[1], w.shape[0], 1, 1, 1))
+        else:
+            out = F.conv3d(x, _dense_weights3(w), padding=1)
+        return out * self.masks[level]
+
+    def down(self, x, name, level):  # kernel 2 stride 2: children -> parent at level + 1
+        return F.conv3d(x, _dense_weights3(self.sd[name + ".kernel"]), stride=2) * self.masks[level + 1]
+
+    def up(self, x, name, level):  # transposed kernel 2 stride 2 onto the EXISTING map of level - 1
+        return F.conv_transpose3d(x, _dense_weights3(self.sd[name + ".kernel"], True), stride=2) * self.masks[level - 1]
+
+    def block(self, x, name, level):  # BasicBlock
+        m = self.masks[level]
+        out = F.relu(self.bn(self.conv(x, name + ".conv1", level), name + ".norm1")) * m
+        out = self.bn(self.conv(out, name + ".conv2", level), name + ".norm2") * m
+        res = x
+        if name + ".downsample.0.kernel" in self.sd:
+            res = self.bn(self.conv(x, name + ".downsample.0", level), name + ".downsample.1") * m
+        return F.relu(out + res) * m
+
+    def stack(self, x, name, level):
+        i = 0
+        while f"{name}.{i}.conv1.kernel" in self.sd:
+            x = self.block(x, f"{name}.{i}", level)
+            i += 1
+        return x
+
+    def forward(self, x):
+        m = self.masks
+        out_p1 = F.relu(self.bn(self.conv(x, "conv0p1s1", 0), "bn0")) * m[0]
+        skips, out = [out_p1], out_p1
+        for i in range(1, 5):
+            out = F.relu(self.bn(self.down(out, f"conv{i}p{2 ** (i - 1)}s2", i - 1), f"bn{i}")) * m[i]
+            out = self.stack(out, f"block{i}", i)
+            skips.append(out)
+        out = skips.pop()
+        for j in range(4, 8):
+            level = 8 - j  # input level of the transposed conv
+            out = F.relu(self.bn(self.up(out, f"convtr{j}p{2 ** level}s2", level), f"bntr{j}")) * m[level - 1]
+            out = torch.cat([out, skips.pop()], dim=1)
+            out = self.stack(out, f"block{j + 1}", level - 1)
+        w, b = self.sd["final.kernel"].double(), self.sd["final.bias"].double().view(1, -1, 1, 1, 1)
+        return (F.conv3d(out, w.t().reshape(w.shape[1], w.shape[0], 1, 1, 1)) + b) * m[0]
+
+
+def _cloud(seed, n):
+    """integer voxel coordinates in [-16, 16)^3: a sphere shell, a slab and scattered single voxels."""
+    rng = np.random.default_rng(seed)
+    d = rng.normal(size=(n, 3))
+    shell = d / np.linalg.norm(d, axis=1, keepdims=True) * rng.uniform(10.5, 12.5, size=(n, 1)) + rng.uniform(-2, 2, 3)
+    slab = np.concatenate([rng.uniform(-16, 16, size=(n // 2, 2)), rng.uniform(-3.2, -1.1, size=(n // 2, 1))], axis=1)
+    lone = rng.uniform(-16, 16, size=(40, 3))
+    c = np.floor(np.concatenate([shell, slab, lone])).astype(np.int64)
+    c = np.unique(c[(np.abs(c + 0.5) < 16).all(axis=1)], axis=0)
+    return c[rng.permutation(len(c))]
+
+
+def test_minkunet14a_matches_dense_grid_float64(gpu):
+    from mrcc_amd import MinkowskiEngine as ME
+    from mrcc_amd.model.backbone.minkunet import MinkUNet14A
+
+    torch.manual_seed(21)
+    net = MinkUNet14A(3, 20)
+    g = torch.Generator().manual_seed(22)
+    with torch.no_grad():
+        for mod in net.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.weight.copy_(torch.rand(mod.num_features, generator=g) * 0.5 + 0.75)
+                mod.bias.copy_(torch.randn(mod.num_features, generator=g) * 0.1)
+                mod.running_mean.copy_(torch.randn(mod.num_features, generator=g) * 0.1)
+                mod.running_var.copy_(torch.rand(mod.num_features, generator=g) * 0.5 + 0.75)
+    net = net.to(gpu).eval()
+    clouds = [_cloud(1, 2500), _cloud(2, 900)]  # two frames in one batch
+    assert all(c.min() < -10 and c.max() > 10 for c in clouds)
+    rng = np.random.default_rng(3)
+    feats = [rng.uniform(-0.5, 0.5, size=(len(c), 3)).astype(np.float32) for c in clouds]
+    coords4 = np.concatenate([np.concatenate([np.full((len(c), 1), b, np.int64), c], axis=1)
+                              for b, c in enumerate(clouds)])
+    with torch.no_grad():
+        x = ME.SparseTensor(torch.from_numpy(np.concatenate(feats)), coordinates=torch.from_numpy(coords4).int(),
+                            device=gpu)
+        out = net(x)
+    got = out.F.cpu().numpy().astype(np.float64)
+    oc = out.C.cpu().numpy().astype(np.int64)  # (batch, x, y, z) of every output row
+    # ---- the dense side: [N, C, Z, Y, X]
+    dense = torch.zeros((2, 3, G, G, G), dtype=torch.float64)
+    m0 = torch.zeros((2, 1, G, G, G), dtype=torch.float64)
+    for b, (c, f) in enumerate(zip(clouds, feats)):
+        s = c + OFF
+        dense[b, :, s[:, 2], s[:, 1], s[:, 0]] = torch.from_numpy(f.astype(np.float64)).t()
+        m0[b, 0, s[:, 2], s[:, 1], s[:, 0]] = 1.0
+    masks = [m0]
+    for _ in range(4):
+        masks.append(F.max_pool3d(masks[-1], 2))  # a coarse voxel exists iff one of its 8 children does
+    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+    want_dense = DenseNet(net.state_dict(), masks).forward(dense)
+    want = want_dense[oc[:, 0], :, oc[:, 3] + OFF, oc[:, 2] + OFF, oc[:, 1] + OFF].numpy()
+    assert got.shape == want.shape == (sum(len(c) for c in clouds), 20)
+    scale = np.abs(want).max()
+    err = np.abs(got - want).max()
+    assert scale > 0.05 and err < 1e-4 * max(1.0, scale), (err, scale)
+    # the sparse output lives exactly on the input's voxel set, level by level
+    cm = x.coordinate_manager
+    for level in range(5):
+        assert cm.stride_map(1 << level).V == int(masks[level].sum().item())

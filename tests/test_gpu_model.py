@@ -174,3 +174,79 @@ def test_bottleneck_backbones_bit_exact(gpu, oracle, name):
     want = oracle.minkunet_forward(sd, feats, oracle.Frame(vox["coords"]))
     got = out.F.cpu().numpy()
     assert got.shape == want.shape and np.array_equal(got, want), f"max diff {np.abs(got - want).max()}"
+
+
+def test_reference_shaped_model_code_on_the_installed_namespace(gpu):
+    """The drop-in boundary used the way the reference uses it: `import MinkowskiEngine as ME` resolves to this build
+    (mrcc_amd.install_as_minkowski_engine()), and a forward pass WRITTEN LIKE the reference's model files - explicit
+    conv -> bn -> relu module calls, ME.cat, ME's BasicBlock recipe with `out += residual`
+    (model/backbone/minkunet.py:125-187) - gives the same bits as the fused mirror."""
+    import importlib
+    import sys
+
+    import mrcc_amd
+
+    me = mrcc_amd.install_as_minkowski_engine()
+    import MinkowskiEngine as ME
+    from MinkowskiEngine.modules.resnet_block import BasicBlock, Bottleneck
+    import MinkowskiEngine.MinkowskiOps as MEOps
+
+    assert ME is me and sys.modules["MinkowskiEngine.utils"] is me.utils
+    assert BasicBlock.expansion == 1 and Bottleneck.expansion == 4 and hasattr(MEOps, "MinkowskiLinear")
+    assert ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE and ME.MinkowskiAlgorithm.SPEED_OPTIMIZED
+    from mrcc_amd.model.backbone.minkunet import MinkUNet14A
+
+    def block_forward(blk, x):  # MinkowskiEngine/modules/resnet_block.py BasicBlock.forward, as published
+        residual = x
+        out = blk.conv1(x)
+        out = blk.norm1(out)
+        out = blk.relu(out)
+        out = blk.conv2(out)
+        out = blk.norm2(out)
+        if blk.downsample is not None:
+            residual = blk.downsample(x)
+        out += residual
+        return blk.relu(out)
+
+    def stack_forward(seq, x):
+        for blk in seq:
+            x = block_forward(blk, x)
+        return x
+
+    def reference_forward(net, x):  # the statement sequence of model/backbone/minkunet.py:125-187
+        out = net.conv0p1s1(x)
+        out = net.bn0(out)
+        out_p1 = net.relu(out)
+        skips = [out_p1]
+        out = out_p1
+        for conv, bn, block in (("conv1p1s2", "bn1", "block1"), ("conv2p2s2", "bn2", "block2"),
+                                ("conv3p4s2", "bn3", "block3"), ("conv4p8s2", "bn4", "block4")):
+            out = getattr(net, conv)(out)
+            out = getattr(net, bn)(out)
+            out = net.relu(out)
+            out = stack_forward(getattr(net, block), out)
+            skips.append(out)
+        skips.pop()
+        for conv, bn, block in (("convtr4p16s2", "bntr4", "block5"), ("convtr5p8s2", "bntr5", "block6"),
+                                ("convtr6p4s2", "bntr6", "block7"), ("convtr7p2s2", "bntr7", "block8")):
+            out = getattr(net, conv)(out)
+            out = getattr(net, bn)(out)
+            out = net.relu(out)
+            out = ME.cat(out, skips.pop())
+            out = stack_forward(getattr(net, block), out)
+        return net.final(out)
+
+    torch.manual_seed(15)
+    net = MinkUNet14A(3, 12)
+    _randomize_bn(net, 16)
+    net = net.to(gpu).eval()
+    pts, rgb, lab, coords4 = _cloud(7000, 0.6, 17, 50)
+    with torch.no_grad():
+        field = ME.TensorField(features=torch.from_numpy(rgb), coordinates=torch.from_numpy(coords4),
+                               quantization_mode=ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE,
+                               minkowski_algorithm=ME.MinkowskiAlgorithm.SPEED_OPTIMIZED, device=gpu)
+        x = field.sparse()
+        fused = net(x)
+        unfused = reference_forward(net, x)
+        assert unfused.tensor_stride == 1 and torch.equal(fused.F, unfused.F)
+        assert torch.equal(unfused.slice(field).F, fused.F[field.inverse_mapping])

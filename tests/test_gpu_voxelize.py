@@ -149,3 +149,43 @@ def test_empty_and_single_point_inputs_run_through_a_network(gpu):
             assert out.F.shape == (x.F.shape[0], 5)
             label, conf = out.slice_argmax(field)
             assert label.shape == (n,) and (n == 0 or torch.isfinite(out.F).all())
+
+
+@pytest.mark.parametrize("cols,as_torch", [(3, False), (4, False), (3, True)])
+def test_sparse_quantize_matches_oracle(gpu, oracle, cols, as_torch):
+    """A2: ME.utils.sparse_quantize (data/alivev2.py:290-296): first-occurrence representative per voxel, label
+    collisions -> ignore_label, negative coordinates floor towards -inf, return_index / return_inverse."""
+    from mrcc_amd import MinkowskiEngine as ME
+
+    rng = np.random.default_rng(cols)
+    n, qs = 20_000, 0.02
+    pts = rng.uniform(-0.4, 0.4, size=(n, 3)).astype(np.float32)
+    pts[:500] = pts[500:1000] + np.float32(1e-4)          # guaranteed multi-point voxels
+    pts[1000:1010] = np.float32(-qs) * np.arange(10, dtype=np.float32)[:, None]  # exact negative multiples of the size
+    coords = pts if cols == 3 else np.concatenate([rng.integers(0, 3, size=(n, 1)).astype(np.float32) * np.float32(qs),
+                                                   pts], axis=1)
+    feats = rng.normal(size=(n, 3)).astype(np.float32)
+    labels = rng.integers(0, 3, size=n).astype(np.int32)
+    labels[:500] = labels[500:1000]                       # some shared voxels agree on the label ...
+    labels[100:200] = (labels[600:700] + 1) % 3           # ... and some collide
+    wc, wf, wl, widx, winv = oracle.sparse_quantize(coords, feats, labels, qs, ignore_label=255)
+    conv = (lambda a: torch.from_numpy(a)) if as_torch else (lambda a: a)
+    gc, gf, gl, gidx, ginv = ME.utils.sparse_quantize(conv(coords), features=conv(feats), labels=conv(labels),
+                                                      quantization_size=qs, ignore_label=255, return_index=True,
+                                                      return_inverse=True)
+    back = (lambda a: a.numpy()) if as_torch else (lambda a: a)
+    assert isinstance(gc, torch.Tensor) == as_torch
+    assert np.array_equal(back(gc), wc) and np.array_equal(back(gidx), widx) and np.array_equal(back(ginv), winv)
+    assert np.array_equal(back(gf), wf) and np.array_equal(back(gl), wl) and back(gl).dtype == labels.dtype
+    assert (wl == 255).sum() >= 50 and (wl != 255).sum() > 1000 and len(wc) < n - 400
+    # representative = lowest original index of the voxel; every point maps to the voxel holding floor(coord / size)
+    first_of = np.full(len(wc), n, np.int64)
+    np.minimum.at(first_of, winv, np.arange(n))
+    assert np.array_equal(first_of, back(gidx))
+    assert np.array_equal(back(gc)[back(ginv)][:, -3:], np.floor(pts.astype(np.float64) / qs).astype(np.int32))
+    # the three-value form the reference unpacks, and the maps-only form
+    c3, f3, l3 = ME.utils.sparse_quantize(coordinates=coords, features=feats, labels=labels, quantization_size=qs,
+                                          ignore_label=255)
+    assert np.array_equal(c3, wc) and np.array_equal(f3, wf) and np.array_equal(l3, wl)
+    m_idx, m_inv = ME.utils.sparse_quantize(coords, quantization_size=qs, return_maps_only=True, return_inverse=True)
+    assert np.array_equal(m_idx, widx) and np.array_equal(m_inv, winv)

@@ -132,3 +132,35 @@ def test_segmentation_metrics_and_synth():
     assert 0.8 < m["miou"] < 1.0 and 0.9 < m["accuracy"] < 1.0  # reference "accuracy" = (sensitivity + specificity)/2
     plain = M.segmentation_metrics_from_confusion(M.confusion_matrix(pred, lab, 3))
     assert abs(plain["accuracy"] - 0.95) < 1e-9 and abs(plain["miou"] - m["miou"]) < 1e-12
+
+
+def test_kernel_offset_permutation_is_applied_when_loading():
+    """nn.KERNEL_OFFSET_PERMUTATION: the hook for a checkpoint whose kernel-offset numbering differs (it was
+    documented but never read)."""
+    from mrcc_amd import nn as svnn
+    from mrcc_amd.model.backbone.minkunet import MinkUNet14A
+
+    torch.manual_seed(0)
+    src = MinkUNet14A(3, 4)
+    sd = src.state_dict()
+    dst = MinkUNet14A(3, 4)
+    rev27 = list(range(26, -1, -1))  # e.g. a z-fastest reflected numbering
+    try:
+        svnn.KERNEL_OFFSET_PERMUTATION = {27: rev27}
+        dst.load_state_dict(sd)
+    finally:
+        svnn.KERNEL_OFFSET_PERMUTATION = None
+    assert torch.equal(dst.conv0p1s1.kernel, sd["conv0p1s1.kernel"][rev27])
+    assert torch.equal(dst.block8[0].conv2.kernel[3], sd["block8.0.conv2.kernel"][23])
+    assert torch.equal(dst.conv1p1s2.kernel, sd["conv1p1s2.kernel"])  # volume 8: no entry -> untouched
+    assert torch.equal(dst.final.kernel, sd["final.kernel"]) and torch.equal(sd["conv0p1s1.kernel"], src.conv0p1s1.kernel)
+    dst.load_state_dict(sd)  # hook off again: plain copy
+    assert torch.equal(dst.conv0p1s1.kernel, sd["conv0p1s1.kernel"])
+    import pytest
+
+    with pytest.raises(ValueError):
+        try:
+            svnn.KERNEL_OFFSET_PERMUTATION = {8: [0, 0, 1, 2, 3, 4, 5, 6]}
+            dst.load_state_dict(sd)
+        finally:
+            svnn.KERNEL_OFFSET_PERMUTATION = None

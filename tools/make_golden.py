@@ -3,7 +3,10 @@
 Runs only in the build container (the reference never travels to the GPU box); the fixtures it writes are data:
 inputs and the reference's outputs.  Two dev-only imports the reference drags in are satisfied with empty modules:
 `ipdb` (utils/transformation.py:4, a debugger that is never called) and `turtle` (utils/calibration.py:1, an unused
-`from turtle import pos`).
+`from turtle import pos`).  The reference's utils/output.py does `import MinkowskiEngine as ME` (for a type annotation):
+MinkowskiEngine is not installable here, so this build's own ME-shaped namespace is registered under that name
+(mrcc_amd.install_as_minkowski_engine() - the drop-in boundary doing its job); the two functions taken from that file,
+get_pred_center and get_key_point_predictions, are pure torch/numpy and never touch ME.
 
     python tools/make_golden.py          # rewrites tests/golden/{kabsch,quat_avg,add,fps,ball_query,preprocess}.npz
 """
@@ -22,7 +25,13 @@ _turtle.pos = None
 sys.modules.setdefault("turtle", _turtle)
 sys.path.insert(0, REF)
 
+sys.path.insert(1, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mrcc_amd  # noqa: E402
+
+mrcc_amd.install_as_minkowski_engine()
+
 from utils import transformation as T  # noqa: E402
+from utils import output as Out  # noqa: E402
 from utils import calibration as Cal  # noqa: E402
 from utils import metrics as Mx  # noqa: E402
 from utils import preprocess as Pre  # noqa: E402
@@ -200,11 +209,63 @@ def gen_preprocess(rng):
                 rgb01=rgb01, rgb01_out=Pre.normalize_colors(rgb01), norm_points=Pre.normalize_points(pts))
 
 
+def gen_calib_chain(rng):
+    """utils/transformation.py:225-266 (get_base2cam_pose, transform_pose2pose), :63-101 (matrix <-> pose helpers):
+    the chain InferenceEngine.calibrate runs per frame (app/inference_engine.py:152-244)."""
+    B = 48
+    ee2cam = np.zeros((B, 7)); ee2robot = np.zeros((B, 7)); base2cam = np.zeros((B, 7)); p2p = np.zeros((B, 7))
+    mat = np.zeros((B, 4, 4)); mat_inv = np.zeros((B, 4, 4)); pose_back = np.zeros((B, 7))
+    for b in range(B):
+        ee2cam[b, :3] = rng.uniform(-1, 1, 3); ee2cam[b, 3:] = rand_quat(rng)
+        ee2robot[b, :3] = rng.uniform(-1, 1, 3); ee2robot[b, 3:] = rand_quat(rng)
+        if b % 5 == 0:  # near-180-degree rotations exercise every branch of the matrix -> quaternion conversion
+            ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+            ang = np.pi - 1e-3 * (b // 5)
+            ee2cam[b, 3:] = np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * ax])
+        base2cam[b] = T.get_base2cam_pose(ee2cam[b], ee2robot[b])
+        p2p[b] = T.transform_pose2pose(ee2cam[b], ee2robot[b])
+        mat[b] = T.get_transformation_matrix(ee2cam[b], switch_w=False)
+        mat_inv[b] = T.get_transformation_matrix_inverse(mat[b])
+        pose_back[b] = T.get_pose_from_matrix(mat[b])
+    return dict(ee2cam=ee2cam, ee2robot=ee2robot, base2cam=base2cam, pose2pose=p2p, matrix=mat, matrix_inverse=mat_inv,
+                pose_from_matrix=pose_back)
+
+
+def gen_output_ops(rng):
+    """utils/output.py:45-64 get_pred_center (top-8 vote mean, optional quaternion offset) and :81-87
+    get_key_point_predictions (softmax over classes, max over points per class, threshold)."""
+    n = 3000
+    votes = rng.normal(size=(n, 2)).astype(np.float32)
+    coords = rng.uniform(-0.5, 0.5, size=(n, 3)).astype(np.float32)
+    centre = Out.get_pred_center(torch.from_numpy(votes), coords)
+    q = rand_quat(rng).astype(np.float32)
+    centre_q = Out.get_pred_center(torch.from_numpy(votes), coords.copy(), ee_r=0.03, q=q)
+    m = 2500
+    logits = (rng.normal(size=(m, 6)) * 2).astype(np.float32)
+    for c, row in zip((0, 2, 3, 5), (17, 400, 1234, 2499)):  # four confident key points, two classes left uncertain
+        logits[row, c] += 25.0
+    idx, classes, probs = Out.get_key_point_predictions(torch.from_numpy(logits))
+    idx9, classes9, probs9 = Out.get_key_point_predictions(torch.from_numpy(logits), conf_th=0.5)
+    seg_logits = rng.normal(size=(2000, 3)).astype(np.float32)
+
+    class _Field:
+        features = torch.from_numpy(seg_logits)
+
+    preds, conf = Out.get_segmentations_from_tensor_field(_Field())
+    return dict(votes=votes, coords=coords, centre=np.asarray(centre, np.float64), q=q,
+                centre_q=np.asarray(centre_q, np.float64), kp_logits=logits, kp_idx=np.asarray(idx, np.int64),
+                kp_classes=np.asarray(classes, np.int64), kp_probs=np.asarray(probs, np.float32),
+                kp_idx_th05=np.asarray(idx9, np.int64), kp_classes_th05=np.asarray(classes9, np.int64),
+                kp_probs_th05=np.asarray(probs9, np.float32), seg_logits=seg_logits, seg_preds=preds.astype(np.int64),
+                seg_conf=conf.astype(np.float32))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     for name, fn, seed in [("kabsch", gen_kabsch, 100), ("quat_avg", gen_quat_avg, 101), ("add", gen_add, 102),
                            ("fps", gen_fps, 103), ("ball_query", gen_ball_query, 104),
-                           ("preprocess", gen_preprocess, 105), ("metrics", gen_metrics, 106)]:
+                           ("preprocess", gen_preprocess, 105), ("metrics", gen_metrics, 106),
+                           ("calib_chain", gen_calib_chain, 107), ("output_ops", gen_output_ops, 108)]:
         data = fn(np.random.default_rng(seed))
         path = os.path.join(OUT, name + ".npz")
         np.savez_compressed(path, **data)
