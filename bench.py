@@ -63,10 +63,22 @@ import torch  # noqa: E402
 # streams besides torch's default one, and two compute streams sharing a queue would serialise.  Must be set before HIP
 # initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# idle OpenMP workers sleep instead of spinning: the oracle's team (cpu_baseline / accuracy legs) and torch's CPU pool
+# are both as wide as the host
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 
 import mrcc_amd  # noqa: E402
 from mrcc_amd import MinkowskiEngine as ME  # noqa: E402
 from mrcc_amd import profiling  # noqa: E402
+
+_T0 = time.perf_counter()
+
+
+def _log(msg):
+    """progress line on stderr (stdout carries only the JSON line)"""
+    sys.stderr.write(f"[bench {time.perf_counter() - _T0:7.1f}s] {msg}\n")
+    sys.stderr.flush()
+
 
 POINTS = 200_000
 ROOM = 2.4
@@ -148,29 +160,20 @@ def oracle_pass(model, budget_s=25.0):
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     sd = {k: v.cpu() for k, v in model.state_dict().items()}
     pts, rgb, lab = mrcc_amd.synth.gen_room(POINTS // 4, ROOM / 2, 0)
+    _log(f"cpu baseline: oracle on a quarter-size frame, {cores} host threads")
     t0 = time.perf_counter()
     r = O.predict_segmentation(sd, pts, rgb, SCALE)
     t_small = time.perf_counter() - t0
     v_small = len(r["vox"]["keys"])
+    _log(f"cpu baseline: quarter frame took {t_small:.2f} s; gather-GEMM (torch.mm) formulation next")
     checked = dict(pts=pts, rgb=rgb, lab=lab, ref=r, what=f"quarter-size frame ({POINTS // 4} pts, {v_small} voxels)")
     note = ("scalar order-preserving fmaf chain per output row (the bit-exact oracle, AVX2 across output channels, "
             "OpenMP over rows) - NOT a BLAS gather-GEMM; see cpu_baseline_gather_gemm for that")
     est_full = t_small * 4.0
-    # second CPU baseline, as SURVEY.md 8(d) describes the reference's CPU path: per kernel offset gather rows,
-    # torch.mm (MKL/OpenBLAS sgemm on all cores), scatter-add - on the quarter frame
-    torch.set_num_threads(cores)
-    t0 = time.perf_counter()
-    with _gather_gemm_conv(O):
-        r_mm = O.predict_segmentation(sd, pts, rgb, SCALE)
-    t_mm = time.perf_counter() - t0
-    mm = {"value": 1.0 / (4.0 * t_mm), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-          "sample": f"quarter-size frame ({POINTS // 4} pts, L={ROOM / 2} m, {v_small} voxels) took {t_mm:.2f} s; "
-                    f"value = 1 / (4 x that)",
-          "note": "same graph with every conv as gather -> torch.mm -> scatter-add per kernel offset (what "
-                  "MinkowskiEngine's CPU path does); sgemm reassociates sums, so labels agree with the chain oracle "
-                  f"on {float((r_mm['label'] == r['label']).mean()):.6f} of the points, not bit-exactly"}
+    mm = gather_gemm_baseline(sd, r["label"])
     if est_full <= budget_s:
         pts, rgb, lab = mrcc_amd.synth.gen_room(POINTS, ROOM, 0)
+        _log("cpu baseline: oracle on the full 200k-point frame")
         t0 = time.perf_counter()
         r = O.predict_segmentation(sd, pts, rgb, SCALE)
         t_full = time.perf_counter() - t0
@@ -183,6 +186,55 @@ def oracle_pass(model, budget_s=25.0):
                 "sample": f"quarter-size frame ({POINTS // 4} pts, L={ROOM / 2} m, {v_small} voxels) took "
                           f"{t_small:.2f} s; value = 1 / (4 x that): work is linear in voxels", "note": note}
     return base, mm, checked
+
+
+def gather_gemm_baseline(sd, chain_labels, timeout_s=150):
+    """Second CPU baseline, as SURVEY.md 8(d) describes the reference's CPU path: per kernel offset gather rows, torch.mm
+    (sgemm on the host cores), scatter-add - on the quarter frame.  Runs in a CHILD process with its own thread pools
+    : inside this process the oracle's OpenMP team and torch's intra-op pool, both as wide as
+    the host, spin against each other.  Bounded by timeout_s; a failure is reported, never fatal."""
+    import subprocess
+    import tempfile
+
+    cores = len(os.sched_getaffinity(0))
+    threads = min(cores, 64)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "sd.pt")
+        torch.save(sd, path)
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        env.pop("OMP_WAIT_POLICY", None)  # one pool at a time in the child: default (spin-then-sleep) waits
+        env.update(OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+        try:
+            res = subprocess.run([sys.executable, os.path.abspath(__file__), "--gather-gemm-child", path], env=env,
+                                 capture_output=True, text=True, timeout=timeout_s)
+            rec = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+        except (subprocess.TimeoutExpired, IndexError, ValueError) as e:
+            _log(f"cpu baseline: gather-GEMM child failed: {type(e).__name__}")
+            return {"value": None, "unit": "frames/s", "kind": "port", "note": f"not measured: {type(e).__name__}"}
+    agree = rec.pop("label_histogram")
+    _log(f"cpu baseline: gather-GEMM quarter frame took {rec['seconds']:.2f} s on {threads} threads")
+    rec["note"] = ("same graph with every conv as gather -> torch.mm -> scatter-add per kernel offset (what "
+                   "MinkowskiEngine's CPU path does); sgemm reassociates sums, so it is a timing baseline, not the "
+                   f"parity oracle; label histogram {agree} vs the chain oracle's "
+                   f"{np.bincount(chain_labels, minlength=3).tolist()}")
+    return rec
+
+
+def gather_gemm_child(sd_path):
+    """--gather-gemm-child: time the gather-GEMM formulation on the quarter frame; never touches the GPU."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import sv_oracle as O
+
+    sd = torch.load(sd_path)
+    pts, rgb, _ = mrcc_amd.synth.gen_room(POINTS // 4, ROOM / 2, 0)
+    t0 = time.perf_counter()
+    with _gather_gemm_conv(O):
+        r = O.predict_segmentation(sd, pts, rgb, SCALE)
+    t_mm = time.perf_counter() - t0
+    print(json.dumps({"value": 1.0 / (4.0 * t_mm), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                      "seconds": t_mm, "label_histogram": np.bincount(r["label"], minlength=3).tolist(),
+                      "sample": f"quarter-size frame ({POINTS // 4} pts, L={ROOM / 2} m, {len(r['vox']['keys'])} voxels) "
+                                f"took {t_mm:.2f} s; value = 1 / (4 x that)"}), flush=True)
 
 
 class _gather_gemm_conv:
@@ -317,7 +369,13 @@ def main():
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="CPU rehearsal of the N-rank launch: rendezvous (gloo), frame sharding, the one all_gather and "
                          "the JSON line, without touching a GPU (tests/test_dist_cpu.py)")
+    ap.add_argument("--gather-gemm-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.gather_gemm_child:
+        return gather_gemm_child(args.gather_gemm_child)
+    import faulthandler
+
+    faulthandler.dump_traceback_later(300, repeat=True, file=sys.stderr)  # a stuck run says where it is stuck
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -343,6 +401,7 @@ def main():
     torch.cuda.set_device(device)
     mrcc_amd._lib.load()
 
+    _log(f"rank {rank}/{world} on {device}: building the model and {args.pool} resident frames")
     model = build_model(device)
     # rank r owns frames r, r + world, ... of the global seed sequence (Cfg-4 sharding rule)
     frames = [make_frame(rank + world * i, device, batch=args.frames_per_step) for i in range(args.pool)]
@@ -380,6 +439,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
+        _log(f"warm-up done; timing {args.steps} steps")
         t0 = time.perf_counter()
         hist = torch.zeros(3, dtype=torch.int64, device=device)
         voxels = run_frames(model, pipe, frames, args.steps, hist)
@@ -388,6 +448,7 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         profiling.TIMER = None
+    _log(f"timed region: {elapsed * 1e3 / args.steps:.2f} ms/step")
 
     # the run's ONE collective: all_gather of a small per-rank record (RCCL over xGMI when world > 1)
     from mrcc_amd.app.sharding import gather_metrics
@@ -453,11 +514,13 @@ def main():
             # the oracle pass gives both the timed CPU baseline (reported at N = 1, as the contract says) and the
             # reference labels of the accuracy half of the metric (every N; the other ranks wait at the final barrier)
             base, base_mm, checked = oracle_pass(model)
+            _log("accuracy: GPU path vs oracle labels on " + checked["what"])
             line["accuracy"] = accuracy_block(model, device, checked)
             if world == 1:
                 line["cpu_baseline"] = base
                 line["cpu_baseline_gather_gemm"] = base_mm
         print(json.dumps(line), flush=True)
+    faulthandler.cancel_dump_traceback_later()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -95,7 +95,11 @@ struct ConvCfg {
   // the FULL form (see the kernel) pays where a k-step is one or two matrix ops and the per-k-step bookkeeping of
   // the general form dominates; on the 64-row tile it costs the 129th VGPR (3 instead of 4 waves per SIMD) and on
   // 16x128 tiles it measured slower (profiles/r01_conv_full_form.txt)
+#ifdef SV_EXP_FULL64
+  static constexpr bool USE_FULL = (MR * NT == 1) || (TM_ == 32 && WAVES_N == 4 && NT == 3) || (TM_ == 16 && NT == 3) || (TM_ == 64 && WAVES_N == 4);
+#else
   static constexpr bool USE_FULL = (MR * NT == 1) || (TM_ == 32 && WAVES_N == 4 && NT == 3) || (TM_ == 16 && NT == 3);
+#endif
   static constexpr int F4_PER_ROW = KC / 4;      // float4 per gathered row and step
   static constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
   static constexpr int A_F4 = (TM_ + ROWS_PER_PASS - 1) / ROWS_PER_PASS;  // float4 gathers per thread and step
@@ -278,8 +282,13 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
     }
   };
 
-  // B operands of one k-step: rows c0 + 4 ks + lq of W[k], NT consecutive output channels starting at col0
-  float b[KC / 4][NT];
+  // B operands of one k-step: rows c0 + 4 ks + lq of W[k], NT consecutive output channels starting at col0.  Each
+  // k-step's NT values are ONE register tuple (the destination of one global_load_dwordxNT): kept as a vector value the
+  // loop carries it as a tuple, and the reload lands in the registers the next step's matrix ops read (as NT separate
+  // floats the tuple was copied element by element at the loop back-edge, behind an s_waitcnt vmcnt(0))
+  typedef float bvec_t __attribute__((ext_vector_type(NT)));
+  typedef float bvec_load_t __attribute__((ext_vector_type(NT), aligned(4)));
+  bvec_t b[KC / 4];
   // FAST: wstep = first weight row of the step (wave-uniform -> scalar registers), b_off = this lane's constant offset;
   // per k-step only a scalar add remains.  K-steps past the channel tail re-read row 0 of the step (never multiplied).
   const int b_off = lq * Cout + col0;
@@ -287,11 +296,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
   // valid A columns of the step starting at (k, c0): the rest of the chunk is zero padding
   auto cols_of = [&](int k, int c0) { return CPO ? min(GK, K - k) * CPO : min(KC, Cin - c0); };
   auto ksteps_of = [&](int k, int c0) { return (cols_of(k, c0) + 3) >> 2; };
-  auto load_b = [&](const float* wstep, int k, int c0, int ksteps_valid, int ks, float (&dst)[NT]) {
+  auto load_b = [&](const float* wstep, int k, int c0, int ksteps_valid, int ks, bvec_t& dst) {
     if (FAST) {
       const float* src = wstep + (int64_t)(ks < ksteps_valid ? 4 * ks : 0) * Cout;
-#pragma unroll
-      for (int n = 0; n < NT; ++n) dst[n] = src[b_off + n];
+      dst = *(const bvec_load_t*)(src + b_off);
     } else {
       // W row of A column i of the step: (k * Cin + c0 + i) - fused offsets are consecutive row blocks of W
       const int i = 4 * ks + lq;
@@ -337,8 +345,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
         auto reload_b = [&](int ks) {
           if (FULL) {
             const float* src = wnext + (int64_t)(4 * ks) * Cout;
-#pragma unroll
-            for (int n = 0; n < NT; ++n) b[ks][n] = src[b_off + n];
+            b[ks] = *(const bvec_load_t*)(src + b_off);
           } else if (FAST || have_n) {
             load_b(wnext, kb, c_n, ksteps_next, ks, b[ks]);
           }
