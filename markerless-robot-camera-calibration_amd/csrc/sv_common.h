@@ -117,4 +117,11 @@ int launch_unique_sorted(const uint64_t* sorted_keys, int64_t n, uint64_t clear_
                          int32_t* block_counts, int32_t* total /*device int32*/, hipStream_t stream);
 size_t unique_sorted_blocks(int64_t n);
 
+// Stable LSD radix sort of (key, int32 value) pairs by key bits [begin_bit, end_bit) (sv_sort.hip).  vals_in == nullptr
+// sorts the identity permutation.  Outputs must not alias the inputs; temp holds radix_sort_temp_bytes(n, sizeof(KeyT)).
+size_t radix_sort_temp_bytes(int64_t n, size_t key_bytes);
+template <typename KeyT>
+int radix_sort_pairs(const KeyT* keys_in, const int32_t* vals_in, KeyT* keys_out, int32_t* vals_out, int64_t n,
+                     int begin_bit, int end_bit, void* temp, size_t temp_bytes, hipStream_t stream);
+
 }  // namespace sv

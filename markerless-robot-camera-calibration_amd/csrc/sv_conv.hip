@@ -796,8 +796,12 @@ static int select_and_launch(const ConvParams& p, hipStream_t stream) {
   // duration is the serial (offset, chunk) chain of one of them: 16-row tiles with 128-channel chunks are fastest
   // there (tools/sweep_small.sh, profiles/r01_conv_small_level_sweep.txt).
   static const Candidate wide3[] = {{64, 4, 3, 2500}, {32, 4, 3, 1500}, {32, 2, 3, 0}};
-  // Cout % 128 == 0 (384): settled-clock sweep of the mid levels, profiles/r01_conv_mid_level_sweep.txt
-  static const Candidate wide3_128[] = {{64, 4, 3, 2500}, {64, 4, 2, 1200}, {16, 4, 3, 800}, {16, 4, 2, 0}};
+  // Cout % 128 == 0 (384): settled-clock sweeps of every level, profiles/r02_conv_instance_sweep.txt.  Below the
+  // chip-filling size the 16-row tile in its FULL form (Cin a multiple of its 128-channel step: 384, 512) wins at every
+  // level (level 1: 96.4 TFLOP/s against 90.1 for 64x128, level 3: 41 against 34 for 16x128); with a partial last chunk
+  // (Cin 416 / 448, the first conv after a concatenation) it only wins once 64x128 tiles no longer fill the chip
+  static const Candidate wide3_128[] = {{64, 4, 3, 2500}, {64, 4, 2, 1200}, {16, 4, 3, 0}};
+  static const Candidate wide3_128_full[] = {{64, 4, 3, 2500}, {16, 4, 3, 0}};
   static const Candidate wide2[] = {{128, 4, 2, 1300}, {64, 4, 2, 1500}, {32, 4, 2, 1500}, {32, 2, 2, 0}};
   static const Candidate wide2_64[] = {{128, 4, 2, 1300}, {64, 4, 2, 1500}, {32, 4, 2, 1500}, {16, 4, 1, 0}};  // % 64
   static const Candidate c64[] = {{64, 4, 1, 1500}, {32, 4, 1, 1500}, {16, 4, 1, 0}};
@@ -806,7 +810,11 @@ static int select_and_launch(const ConvParams& p, hipStream_t stream) {
   const Candidate* list;
   int n;
   const int Cout = p.Cout;
-  if (Cout > 128 && (Cout % 192 == 0 || Cout % 96 == 0 || Cout > 2048)) { list = Cout % 128 == 0 ? wide3_128 : wide3; n = Cout % 128 == 0 ? 4 : 3; }
+  if (Cout > 128 && (Cout % 192 == 0 || Cout % 96 == 0 || Cout > 2048)) {
+    if (Cout % 128 != 0) { list = wide3; n = 3; }
+    else if (p.Cin % 128 == 0 && p.vec_a) { list = wide3_128_full; n = 2; }
+    else { list = wide3_128; n = 3; }
+  }
   else if (Cout > 64) { list = Cout % 64 == 0 ? wide2_64 : wide2; n = 4; }
   else if (Cout > 32) { list = c64; n = 3; }
   else if (Cout > 16) { list = c32; n = 3; }

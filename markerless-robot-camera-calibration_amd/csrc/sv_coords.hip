@@ -6,7 +6,6 @@
 // point/voxel, coalesced row-id tables, wave ballot + popcount prefix sums for compaction, no float atomics.
 #include <cstring>
 
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "sv_common.h"
 
@@ -233,34 +232,37 @@ __global__ __launch_bounds__(256) void stride_scatter_kernel(const uint64_t* __r
 // ------------------------------------------------------------------------------------------------
 // kernel maps
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void kmap_k3_kernel(const int32_t* __restrict__ vcoords, int64_t V, int step,
-                                                       const uint64_t* __restrict__ tkeys,
-                                                       const int32_t* __restrict__ tvals, uint64_t cap_mask,
-                                                       int32_t* __restrict__ nbr, int64_t ld,
-                                                       uint32_t* __restrict__ mask) {
-  int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+// One THREAD per (voxel, offset) probe: blockIdx.y = offset k, so a workgroup resolves offset k for 256 consecutive voxels
+// (coalesced coordinate reads and nbr[k][.] writes).  The probe of a neighbour is a dependent chain (hash -> slot -> maybe
+// the next slot) that cannot be pipelined inside a thread; with one probe per thread the 27 V chains overlap through
+// occupancy instead (2.4 M threads at the 2 cm room level), where the thread-per-voxel form of round 1 walked its 27
+// chains one after the other on ~1.3 waves per SIMD (64 us alone on the GPU, ~320 us beside the convolutions).
+__global__ __launch_bounds__(256) void kmap_k3_probe_kernel(const int32_t* __restrict__ vcoords, int64_t V, int step,
+                                                             const uint64_t* __restrict__ tkeys,
+                                                             const int32_t* __restrict__ tvals, uint64_t cap_mask,
+                                                             int32_t* __restrict__ nbr, int64_t ld) {
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (o >= V) return;
-  const int4 c = ((const int4*)vcoords)[o];
-  uint32_t m = 0;
-  int k = 0;
-#pragma unroll
-  for (int dz = -1; dz <= 1; ++dz) {
-#pragma unroll
-    for (int dy = -1; dy <= 1; ++dy) {
-#pragma unroll
-      for (int dx = -1; dx <= 1; ++dx, ++k) {
-        int r;
-        if (dx == 0 && dy == 0 && dz == 0) {
-          r = (int)o;
-        } else {
-          int x = c.y + dx * step, y = c.z + dy * step, z = c.w + dz * step;
-          r = coord_in_range(c.x, x, y, z) ? hash_find(tkeys, tvals, cap_mask, make_key(c.x, x, y, z)) : -1;
-        }
-        nbr[(int64_t)k * ld + o] = r;
-        m |= (r >= 0) ? (1u << k) : 0u;
-      }
-    }
+  const int k = blockIdx.y;
+  const int dx = k % 3 - 1, dy = (k / 3) % 3 - 1, dz = k / 9 - 1;
+  int r;
+  if (k == 13) {
+    r = (int)o;
+  } else {
+    const int4 c = ((const int4*)vcoords)[o];
+    const int x = c.y + dx * step, y = c.z + dy * step, z = c.w + dz * step;
+    r = coord_in_range(c.x, x, y, z) ? hash_find(tkeys, tvals, cap_mask, make_key(c.x, x, y, z)) : -1;
   }
+  nbr[(int64_t)k * ld + o] = r;
+}
+
+// mask[o] = bit k set iff nbr[k][o] >= 0 (27 coalesced reads per voxel)
+__global__ __launch_bounds__(256) void kmap_mask_kernel(const int32_t* __restrict__ nbr, int64_t ld, int K, int64_t V,
+                                                         uint32_t* __restrict__ mask) {
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= V) return;
+  uint32_t m = 0;
+  for (int k = 0; k < K; ++k) m |= (nbr[(int64_t)k * ld + o] >= 0) ? (1u << k) : 0u;
   mask[o] = m;
 }
 
@@ -364,8 +366,8 @@ __global__ __launch_bounds__(256) void tile_cost_kernel(const uint32_t* __restri
   if (t >= tiles) return;
   uint32_t cost = 0;
   for (int k = 0; k < K; ++k) cost += __popc(submask[t * K + k]);
-  key[t] = 0xffffu - cost;  // cost <= 27 * 8
-  idx[t] = (int32_t)t;
+  key[t] = 255u - min(cost, 255u);  // cost <= 27 * 8 = 216: one 8-bit pass
+  (void)idx;
 }
 
 }  // namespace sv
@@ -380,18 +382,8 @@ extern "C" {
 const char* sv_last_error(void) { return sv::g_err; }
 int sv_abi_version(void) { return 1; }
 
-static size_t sort_pairs_u64_temp_bytes(int64_t n) {
-  size_t bytes = 0;
-  rocprim::radix_sort_pairs((void*)nullptr, bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (int32_t*)nullptr,
-                            (int32_t*)nullptr, (size_t)n, 0, 64, (hipStream_t)0);
-  return bytes;
-}
-static size_t sort_pairs_u32_temp_bytes(int64_t n) {
-  size_t bytes = 0;
-  rocprim::radix_sort_pairs((void*)nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr,
-                            (int32_t*)nullptr, (size_t)n, 0, 32, (hipStream_t)0);
-  return bytes;
-}
+static size_t sort_pairs_u64_temp_bytes(int64_t n) { return radix_sort_temp_bytes(n, sizeof(uint64_t)); }
+static size_t sort_pairs_u32_temp_bytes(int64_t n) { return radix_sort_temp_bytes(n, sizeof(uint32_t)); }
 
 size_t sv_voxelize_workspace_bytes(int64_t N) {
   if (N <= 0) return 256;
@@ -432,9 +424,10 @@ int sv_voxelize(const void* coords4, int coords_are_int, int64_t N, void* worksp
   else
     hipLaunchKernelGGL(quantize_kernel<false>, dim3(nb), dim3(256), 0, stream, coords4, N, k_in, i_in, counters);
   SV_LAUNCH_CHECK();
-  SV_HIP(rocprim::radix_sort_pairs((void*)sort_tmp, sort_bytes, k_in, k_sorted, i_in, i_sorted, (size_t)N, 0, 64,
-                                   stream));
-  int rc = launch_unique_sorted(k_sorted, N, ~0ull, rank, blocks, &counters[0], stream);
+  // stable sort by the whole 64-bit key (batch | Morton); values = point indices (identity, generated by the sort)
+  int rc = radix_sort_pairs<uint64_t>(k_in, nullptr, k_sorted, i_sorted, N, 0, 64, sort_tmp, sort_bytes, stream);
+  if (rc) return rc;
+  rc = launch_unique_sorted(k_sorted, N, ~0ull, rank, blocks, &counters[0], stream);
   if (rc) return rc;
   hipLaunchKernelGGL(voxel_scatter_kernel, dim3(nb), dim3(256), 0, stream, k_sorted, i_sorted, rank, N, keys, vcoords,
                      inverse, order, seg_start, &counters[0]);
@@ -508,8 +501,9 @@ int sv_kernel_map_k3(const int32_t* vcoords, int64_t V, int tensor_stride, int d
   SV_CHECK_ARG(capacity >= 2 && (capacity & (capacity - 1)) == 0, "capacity must be a power of two");
   if (V == 0) return SV_OK;
   SV_CHECK_ARG(vcoords && table_keys && table_vals && nbr && mask, "null pointer");
-  hipLaunchKernelGGL(kmap_k3_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, stream, vcoords, V,
-                     tensor_stride * dilation, table_keys, table_vals, (uint64_t)(capacity - 1), nbr, ld, mask);
+  hipLaunchKernelGGL(kmap_k3_probe_kernel, dim3((unsigned)((V + 255) / 256), 27), dim3(256), 0, stream, vcoords, V,
+                     tensor_stride * dilation, table_keys, table_vals, (uint64_t)(capacity - 1), nbr, ld);
+  hipLaunchKernelGGL(kmap_mask_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, stream, nbr, ld, 27, V, mask);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
@@ -576,8 +570,8 @@ int sv_plan_build(const int32_t* nbr, int64_t ld, const uint32_t* mask, int K, i
   hipLaunchKernelGGL(iota_key_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, stream, mask, K, keybits, iota,
                      key, V);
   SV_LAUNCH_CHECK();
-  SV_HIP(rocprim::radix_sort_pairs((void*)sort_tmp, sort_bytes, key, sorted_mask, iota, sorted_rows, (size_t)V, 0,
-                                   (unsigned)K, stream));
+  int rc = radix_sort_pairs<uint32_t>(key, nullptr, sorted_mask, sorted_rows, V, 0, K, sort_tmp, sort_bytes, stream);
+  if (rc) return rc;
   int64_t tiles = Vpad / SV_TILE_ROWS;
   SV_HIP(hipMemsetAsync(submask, 0, (size_t)tiles * K * sizeof(uint32_t), stream));
   hipLaunchKernelGGL(plan_gather_kernel, dim3((unsigned)tiles, (unsigned)K), dim3(128), 0, stream, nbr, ld, sorted_rows,
@@ -587,8 +581,8 @@ int sv_plan_build(const int32_t* nbr, int64_t ld, const uint32_t* mask, int K, i
     hipLaunchKernelGGL(tile_cost_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, submask, K,
                        ntiles, tkey, tidx);
     SV_LAUNCH_CHECK();
-    SV_HIP(rocprim::radix_sort_pairs((void*)tsort_tmp, tsort_bytes, tkey, tkey_sorted, tidx, tile_order,
-                                     (size_t)ntiles, 0, 16, stream));
+    rc = radix_sort_pairs<uint32_t>(tkey, nullptr, tkey_sorted, tile_order, ntiles, 0, 8, tsort_tmp, tsort_bytes, stream);
+    if (rc) return rc;
   }
   return SV_OK;
 }

@@ -11,7 +11,8 @@ TIMER = None  # set by bench.py
 
 _CANDIDATES = {
     "wide3": [(64, 4, 3, 2500), (32, 4, 3, 1500), (32, 2, 3, 0)],
-    "wide3_128": [(64, 4, 3, 2500), (64, 4, 2, 1200), (16, 4, 3, 800), (16, 4, 2, 0)],
+    "wide3_128": [(64, 4, 3, 2500), (64, 4, 2, 1200), (16, 4, 3, 0)],
+    "wide3_128_full": [(64, 4, 3, 2500), (16, 4, 3, 0)],  # Cin a multiple of the 16-row tile's 128-channel step
     "wide2": [(128, 4, 2, 1300), (64, 4, 2, 1500), (32, 4, 2, 1500), (32, 2, 2, 0)],
     "wide2_64": [(128, 4, 2, 1300), (64, 4, 2, 1500), (32, 4, 2, 1500), (16, 4, 1, 0)],
     "c64": [(64, 4, 1, 1500), (32, 4, 1, 1500), (16, 4, 1, 0)],
@@ -44,7 +45,10 @@ def conv_kernel_config(Cout, Vpad, Cin=None, K=1):
     if fused is not None:
         cands = fused
     elif Cout > 128 and (Cout % 192 == 0 or Cout % 96 == 0 or Cout > 2048):
-        cands = _CANDIDATES["wide3_128" if Cout % 128 == 0 else "wide3"]
+        if Cout % 128 != 0:
+            cands = _CANDIDATES["wide3"]
+        else:
+            cands = _CANDIDATES["wide3_128_full" if (Cin is not None and Cin % 128 == 0) else "wide3_128"]
     elif Cout > 64:
         cands = _CANDIDATES["wide2_64" if Cout % 64 == 0 else "wide2"]
     elif Cout > 32:

@@ -107,10 +107,11 @@ def test_strided_input_and_affine(gpu, oracle):
     assert _same(got.cpu().numpy(), oracle.affine_act(big, s, b, None, oracle.ACT_LEAKY, 0.01))
 
 
-@pytest.mark.parametrize("level,cin", [(0, 32), (1, 64), (2, 96), (3, 128)])
+@pytest.mark.parametrize("level,cin", [(0, 32), (1, 64), (1, 128), (2, 96), (3, 128), (3, 96)])
 def test_conv_every_tile_shape_of_the_pyramid_bit_exact(gpu, oracle, level, cin):
     """The Cfg-2 pyramid (88k / 26k / 7k / 2k voxels) with 384 output channels walks the dispatch table of the wide
-    layers: 64x192, 64x128, 16x192 and 16x128 (register-ring) tiles.  Narrow inputs keep the oracle fast."""
+    layers: 64x192, 64x128 and 16x192 (register-ring; FULL form when Cin is a multiple of 128) tiles.  Narrow inputs keep
+    the oracle fast."""
     import mrcc_amd
     from mrcc_amd import MinkowskiEngine as ME
     from mrcc_amd import nn as svnn
@@ -123,8 +124,8 @@ def test_conv_every_tile_shape_of_the_pyramid_bit_exact(gpu, oracle, level, cin)
     ts = 1 << level
     plan = cm.plan_k3(ts)
     V = cm.stride_map(ts).V
-    expect = {0: "conv_fwd_kernel<64, 4, 3>", 1: "conv_fwd_kernel<64, 4, 2>", 2: "conv_fwd_kernel<16, 4, 3>",
-              3: "conv_fwd_kernel<16, 4, 2>"}[level]
+    expect = {0: "conv_fwd_kernel<64, 4, 3>", 1: "conv_fwd_kernel<64, 4, 2>" if cin % 128 else "conv_fwd_kernel<16, 4, 3>",
+              2: "conv_fwd_kernel<16, 4, 3>", 3: "conv_fwd_kernel<16, 4, 3>"}[level]
     assert profiling.conv_kernel_config(384, plan.Vpad, cin, 27) == expect
     frame = oracle.Frame(oracle.voxelize(coords4)["coords"])
     for l in range(level):

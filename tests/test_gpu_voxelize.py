@@ -189,3 +189,53 @@ def test_sparse_quantize_matches_oracle(gpu, oracle, cols, as_torch):
     assert np.array_equal(c3, wc) and np.array_equal(f3, wf) and np.array_equal(l3, wl)
     m_idx, m_inv = ME.utils.sparse_quantize(coords, quantization_size=qs, return_maps_only=True, return_inverse=True)
     assert np.array_equal(m_idx, widx) and np.array_equal(m_inv, winv)
+
+
+def _gray_key(mask, K):
+    """sort key of sv_plan_build (csrc/sv_coords.hip iota_key_kernel): rarest offsets (corners, edges, faces, centre) as
+    the most significant bits, then the rank in reflected-Gray order."""
+    m = mask.astype(np.int64)
+    if K == 27:
+        pos, rank = {}, 0
+        for cls in (3, 2, 1, 0):
+            for k in range(27):
+                if abs(k % 3 - 1) + abs((k // 3) % 3 - 1) + abs(k // 9 - 1) == cls:
+                    pos[k] = 26 - rank
+                    rank += 1
+        m2 = np.zeros_like(m)
+        for k in range(27):
+            m2 |= ((m >> k) & 1) << pos[k]
+        m = m2
+    for s in (1, 2, 4, 8, 16):
+        m ^= m >> s
+    return m
+
+
+@pytest.mark.parametrize("n,L", [(200_000, 2.4), (9_000, 0.6), (300, 0.2)])
+def test_plan_order_is_the_stable_sort_of_its_key(gpu, n, L):
+    """The hand-written radix sort (csrc/sv_sort.hip) behind the conv plans: multi-workgroup passes at the big levels,
+    the one-launch single-workgroup sort at the small ones and for every tile order.  perm must be EXACTLY the stable
+    sort of the rows by their Gray key, tile_order the stable sort of the plan tiles by work, descending."""
+    import mrcc_amd
+    from mrcc_amd import MinkowskiEngine as ME
+
+    pts, rgb, _ = mrcc_amd.synth.gen_room(n, L, 5)
+    c4 = np.concatenate([np.zeros((n, 1), np.float32), pts * np.float32(50)], axis=1)
+    x = ME.TensorField(torch.from_numpy(rgb), torch.from_numpy(c4), device=gpu).sparse()
+    cm = x.coordinate_manager
+    plans = [(cm.plan_k3(1 << l), 27) for l in range(4)] + [(cm.plan_down(1), 8), (cm.plan_up(2), 8), (cm.plan_down(4), 8)]
+    for plan, K in plans:
+        V = plan.V_out
+        perm = plan.perm.cpu().numpy()
+        nbr_s = plan.nbr_s.cpu().numpy()
+        assert np.array_equal(np.sort(perm[:V]), np.arange(V)) and (perm[V:] == -1).all()
+        mask_sorted = np.zeros(plan.Vpad, np.int64)
+        for k in range(K):
+            mask_sorted |= (nbr_s[k] >= 0).astype(np.int64) << k
+        mask = np.zeros(V, np.int64)
+        mask[perm[:V]] = mask_sorted[:V]
+        want = np.argsort(_gray_key(mask, K), kind="stable")
+        assert np.array_equal(perm[:V], want)
+        sub = plan.submask.cpu().numpy().astype(np.uint32)
+        cost = np.array([[bin(int(v)).count("1") for v in row] for row in sub]).sum(axis=1)
+        assert np.array_equal(plan.tile_order.cpu().numpy(), np.argsort(255 - np.minimum(cost, 255), kind="stable"))

@@ -105,10 +105,14 @@ def test_kernel_dispatch_mirror():
     from mrcc_amd.profiling import conv_kernel_config as c
 
     assert c(384, 88192) == "conv_fwd_kernel<64, 4, 3>"
-    assert c(384, 26624) == "conv_fwd_kernel<64, 4, 2>"
+    assert c(384, 26624) == "conv_fwd_kernel<64, 4, 2>"        # Cin unknown / not a multiple of 128
+    assert c(384, 26624, 416, 27) == "conv_fwd_kernel<64, 4, 2>"
+    assert c(384, 26624, 384, 27) == "conv_fwd_kernel<16, 4, 3>"  # FULL form of the 16-row tile
+    assert c(384, 88192, 384, 27) == "conv_fwd_kernel<64, 4, 3>"
     assert c(384, 6912) == "conv_fwd_kernel<16, 4, 3>"
     assert c(192, 26624) == "conv_fwd_kernel<32, 2, 3>"
-    assert c(384, 1792) == "conv_fwd_kernel<16, 4, 2>"
+    assert c(384, 1792) == "conv_fwd_kernel<16, 4, 3>"
+    assert c(384, 1792, 512, 27) == "conv_fwd_kernel<16, 4, 3>"
     assert c(192, 1792) == "conv_fwd_kernel<32, 2, 3>"
     assert c(256, 512) == "conv_fwd_kernel<16, 4, 1>"
     assert c(32, 26624) == "conv_fwd_kernel<32, 2, 1>"
