@@ -335,6 +335,55 @@ def accuracy_block(model, device, checked):
     }
 
 
+def hbm_bound_layers(model, device, iters=60):
+    """The gather-bound layers of the network, each timed as `iters` back-to-back launches on the seed-0 frame (HIP
+    events on the launch stream): achieved GB/s = SURVEY.md 8(d) algorithmic gather-bytes / time, against the 8 TB/s HBM
+    peak.  north_star target: >= 40 % on the sparse-conv gather at 80k active voxels.  (In the frame these launches are
+    16-110 us long; inside the pipelined timed region the first launch of a frame - conv0 - sits behind a cross-stream
+    wait, so it is measured here, where nothing else runs.)"""
+    from mrcc_amd import nn as svnn
+
+    frame = make_frame(0, device)
+    out = {}
+    with torch.no_grad():
+        field = ME.TensorField(frame[1], frame[0], quantization_mode=ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE,
+                               device=device)
+        x = field.sparse()
+        cm = x.coordinate_manager
+        V0, V1 = cm.stride_map(1).V, cm.stride_map(2).V
+        p0, p1 = cm.plan_k3(1), cm.plan_k3(2)
+        blk = model.block1[0]
+        s0, b0 = model.bn0.folded()
+        s1, b1 = blk.norm1.folded()
+        f1 = torch.randn(V1, 32, device=device)
+        f1024 = torch.randn(V0, 1024, device=device)
+        head = model.regression[2]
+        cases = {
+            "conv0 3->32 k27 (level 0)": (x.F, model.conv0p1s1.weight3().detach(), p0, V0, s0, b0),
+            "block1 32->32 k27 (level 1)": (f1, blk.conv1.weight3().detach(), p1, V1, s1, b1),
+            "regression.2 1024->3 (level 0)": (f1024, head.weight3(), None, V0, None, head.linear.bias.detach()),
+        }
+        for name, (f, w, plan, V, sc, sh) in cases.items():
+            K, Cin, Cout = w.shape
+            for _ in range(3):
+                svnn.conv_forward(f, w, plan, V, sc, sh, None, 1)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(iters):
+                svnn.conv_forward(f, w, plan, V, sc, sh, None, 1)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / iters * 1e3
+            P = plan.num_pairs() if plan is not None else V
+            gb = (P * (4.0 * Cin + 8) + 4.0 * V * Cout + 4.0 * K * Cin * Cout) / 1e9
+            Vpad = plan.Vpad if plan is not None else (V + 127) // 128 * 128
+            out[name] = {"kernel": profiling.conv_kernel_config(Cout, Vpad, Cin, K), "rows": int(V), "us_per_launch": round(us, 2),
+                         "algorithmic_MB": round(gb * 1e3, 2), "GBps": round(gb / (us * 1e-6), 1),
+                         "frac_of_hbm_peak": round(gb / (us * 1e-6) / PEAK_HBM_GBS, 4)}
+    return out
+
+
 def launcher_selftest(args, world, rank):
     """What the N-rank launch does around the GPU work, on the CPU: init (gloo), rank r takes frames r, r + world, ...,
     ONE all_gather of the metrics record, max-over-ranks time, rank 0 prints the line."""
@@ -366,6 +415,8 @@ def main():
     ap.add_argument("--streams", type=int, default=2, help="compute streams alternating between frames (1 = single)")
     ap.add_argument("--frames-per-step", type=int, default=1,
                     help="frames fused into one sparse tensor per step (batch column); 1 = the headline workload")
+    ap.add_argument("--batched-frames", type=int, default=4,
+                    help="secondary measurement: this many frames per step in one sparse tensor (0/1 = skip)")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="CPU rehearsal of the N-rank launch: rendezvous (gloo), frame sharding, the one all_gather and "
                          "the JSON line, without touching a GPU (tests/test_dist_cpu.py)")
@@ -449,6 +500,30 @@ def main():
         elapsed = time.perf_counter() - t0
         profiling.TIMER = None
     _log(f"timed region: {elapsed * 1e3 / args.steps:.2f} ms/step")
+    # ---- secondary, separately named configuration: B frames fused into one sparse tensor per step (batch column,
+    #      data/alivev2.py:358-383) through the same pipeline; the headline above stays one frame per step
+    batched = None
+    if args.batched_frames > 1 and args.frames_per_step == 1:
+        bsteps = max(4, args.steps // args.batched_frames)
+        with torch.no_grad():
+            bframes = [make_frame(rank + world * i, device, batch=args.batched_frames) for i in range(2)]
+            run_frames(model, pipe, bframes, 3)
+            pipe.drain()
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            run_frames(model, pipe, bframes, bsteps)
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            tb = time.perf_counter() - tb
+            del bframes
+        batched = {"config": f"cfg2 frames, {args.batched_frames} per step in one sparse tensor (batch column)",
+                   "frames_per_step": args.batched_frames, "steps": bsteps, "ms_per_step": round(tb / bsteps * 1e3, 3),
+                   "value_this_rank": round(bsteps * args.batched_frames / tb, 3), "unit": "frames/s"}
+        _log(f"batched x{args.batched_frames}: {batched['value_this_rank']} frames/s on this rank")
+    hbm_layers = hbm_bound_layers(model, device) if rank == 0 else None
 
     # the run's ONE collective: all_gather of a small per-rank record (RCCL over xGMI when world > 1)
     from mrcc_amd.app.sharding import gather_metrics
@@ -475,12 +550,18 @@ def main():
                 "compute_streams": args.streams,
             }
             # HBM traffic of this kernel from PMC counters (separate rocprofv3 --pmc passes over this command, calibrated
-            # on a known-traffic launch as the MI355X guide prescribes): profiles/r01_traffic.json, GB per launch
+            # on a known-traffic launch as the MI355X guide prescribes): newest profiles/rNN_traffic.json, GB per launch
             try:
-                tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"].get(name)
+                import glob
+
+                tfile = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
+                tj = json.load(open(tfile))
+                tr = tj["kernels"].get(name)
                 if tr:
                     roofline["traffic"] = tr["traffic_GB_per_launch"]
-                    roofline["traffic_unit"] = "GB per launch (PMC, calibrated; profiles/r01_traffic.json)"
+                    roofline["traffic_unit"] = "GB per launch (PMC, calibrated)"
+                    roofline["traffic_source"] = {"file": "profiles/" + os.path.basename(tfile),
+                                                  "collected_at_commit": tj.get("commit", "unknown")}
                     roofline["algorithmic_GB_per_launch"] = round(warm[name]["bytes"] / warm[name]["launches"] / 1e9, 4)
             except (OSError, KeyError, ValueError):
                 pass
@@ -510,6 +591,9 @@ def main():
             "roofline": roofline,
             "kernels_warmup": kernels,
         }
+        line["hbm_bound_layers"] = hbm_layers
+        if batched is not None:
+            line["batched"] = batched
         if not args.no_cpu_baseline:
             # the oracle pass gives both the timed CPU baseline (reported at N = 1, as the contract says) and the
             # reference labels of the accuracy half of the metric (every N; the other ranks wait at the final barrier)

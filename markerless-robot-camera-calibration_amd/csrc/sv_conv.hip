@@ -218,11 +218,21 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
     }
   };
 
-  float4 ra[A_F4];
+  // gathered rows in flight: one register set per step of gather depth.  With GDEPTH = 2 the rows of step s + 2 are
+  // requested at the start of step s and written to LDS at the end of step s + 1 (loop unrolled by two so that the
+  // register sets keep static names).  Measured and NOT used (-DSV_GATHER_DEPTH=2 rebuilds it): the wide layers lose a
+  // wave per SIMD (181 VGPRs: 88 vs 98 TFLOP/s at level 0) and the thin fused-offset layers do not gain (32->32 at level 1:
+  // 36 vs 33 us; 64->64 at level 2: 31 vs 30 us) - with cache-resident gathers the wide layers run no faster either, i.e.
+  // gather latency is not what a step waits for.
+#ifndef SV_GATHER_DEPTH
+#define SV_GATHER_DEPTH 1
+#endif
+  constexpr int GDEPTH = SV_GATHER_DEPTH;
+  float4 ra0[A_F4], ra1[A_F4];  // ra1 is dead (optimised away) at GDEPTH 1
   const int a_cc = (tid % Cfg::F4_PER_ROW) * 4;
   const int a_r = tid / Cfg::F4_PER_ROW;
 
-  auto load_a = [&](int k, int c0, uint32_t sm) {
+  auto load_a = [&](float4 (&ra)[A_F4], int k, int c0, uint32_t sm) {
 #pragma unroll
     for (int j = 0; j < A_F4; ++j) {
       const int r = a_r + ROWS_PER_PASS * j;
@@ -270,7 +280,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
       }
     }
   };
-  auto store_a = [&](float* dstbuf, uint32_t sm) {
+  auto store_a = [&](float4 (&ra)[A_F4], float* dstbuf, uint32_t sm) {
 #pragma unroll
     for (int j = 0; j < A_F4; ++j) {
       const int r = a_r + ROWS_PER_PASS * j;
@@ -312,30 +322,45 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
 
   __syncthreads();  // idx_s visible
   if (have_n) {
-    // ---- prologue: step 0 operands
+    // ---- prologue: operands of step 0 (cur).  x = the step after cur; with GDEPTH = 2 its gathers are already in flight
+    //      and the iterator (n) stands one step further
     int k_c = k_n, c_c = c_n;
     uint32_t sm_c = sm_n;
-    load_a(k_c, c_c, sm_c);
+    load_a(ra0, k_c, c_c, sm_c);
 #pragma unroll
     for (int ks = 0; ks < KC / 4; ++ks) load_b(step_weights(k_c, c_c), k_c, c_c, ksteps_of(k_c, c_c), ks, b[ks]);
-    store_a(As, sm_c);
+    store_a(ra0, As, sm_c);
     advance();
+    int k_x = k_n, c_x = c_n;
+    uint32_t sm_x = sm_n;
+    bool have_x = have_n;
+    if (GDEPTH == 2) {
+      if (FAST || have_x) load_a(ra1, have_x ? k_x : 0, have_x ? c_x : 0, have_x ? sm_x : 0u);
+      if (have_n) advance();
+    }
     __syncthreads();
     int buf = 0;
 
-    for (;;) {
-      // ---- gathers of the NEXT step go out first: they land during this step's matrix work and are written to the
-      //      other LDS buffer at the end of the iteration.  (Issued here rather than after the barrier so that the
-      //      conservative vmcnt(0) hipcc places on the loop back-edge never waits for a gather that was just issued.)
-      if (FAST || have_n) load_a(have_n ? k_n : 0, c_n, sm_n);
+    // one pipeline step; r_issue receives the gathers requested at its start, r_store holds the rows of step x
+    auto step = [&](float4 (&r_issue)[A_F4], float4 (&r_store)[A_F4]) -> bool {
+      // ---- gathers go out first: they land during matrix work and are written to the other LDS buffer at the end of
+      //      this step (GDEPTH 1) or of the next one (GDEPTH 2).  (Issued here rather than after the barrier so that
+      //      a conservative wait on the loop back-edge never waits for a gather that was just issued.)
+      if (GDEPTH == 1) {
+        if (FAST || have_x) load_a(r_issue, have_x ? k_x : 0, have_x ? c_x : 0, have_x ? sm_x : 0u);
+      } else {
+        const bool have2 = have_x && have_n;
+        if (FAST || have2) load_a(r_issue, have2 ? k_n : 0, have2 ? c_n : 0, have2 ? sm_n : 0u);
+      }
       // ---- MFMA over the current step; A operand reads run one k-step ahead of the matrix ops; each k-step's B
-      //      registers are refilled for the NEXT step as soon as the matrix ops that read them are issued
+      //      registers are refilled for step x as soon as the matrix ops that read them are issued
       const float* a_base = As + buf * (TM_ * SA) + (wm * MR * 16 + li) * SA + lq;
       const uint32_t smw = (sm_c >> (wm * MR)) & ((1u << MR) - 1u);
       const int ksteps = ksteps_of(k_c, c_c);
-      const int kb = have_n ? k_n : 0;
-      const float* wnext = step_weights(kb, c_n);
-      const int ksteps_next = ksteps_of(kb, c_n);
+      const int kb = have_x ? k_x : 0;
+      const int cb = have_x ? c_x : 0;
+      const float* wnext = step_weights(kb, cb);
+      const int ksteps_next = ksteps_of(kb, cb);
       // A operands run PFD k-steps ahead of the matrix ops (register ring when PFD > 1): one k-step of a small tile is
       // only MR * NT * 32 cycles of matrix work, less than an LDS round trip, and on the small pyramid levels a wave
       // has no co-resident wave to hide that latency behind.
@@ -346,8 +371,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
           if (FULL) {
             const float* src = wnext + (int64_t)(4 * ks) * Cout;
             b[ks] = *(const bvec_load_t*)(src + b_off);
-          } else if (FAST || have_n) {
-            load_b(wnext, kb, c_n, ksteps_next, ks, b[ks]);
+          } else if (FAST || have_x) {
+            load_b(wnext, kb, cb, ksteps_next, ks, b[ks]);
           }
         };
         auto mfma_row = [&](int ks, const float (&a)[MR]) {
@@ -362,34 +387,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
             }
           }
         };
-        if constexpr (PFD == 1 && !FULL) {
-          float a_cur[MR];
-#pragma unroll
-          for (int s = 0; s < MR; ++s) a_cur[s] = a_base[s * 16 * SA];
-#pragma unroll
-          for (int ks = 0; ks < KC / 4; ++ks) {
-            if (ks < ksteps) {
-              float a_nx[MR];
-              if (ks + 1 < KC / 4) {
-#pragma unroll
-                for (int s = 0; s < MR; ++s) a_nx[s] = a_base[s * 16 * SA + (ks + 1) * 4];
-              }
-#pragma unroll
-              for (int s = 0; s < MR; ++s) {
-                if ((MR == 1 && Cfg::WAVES_M == 1) || ((smw >> s) & 1u)) {
-#pragma unroll
-                  for (int n = 0; n < NT; ++n)
-                    acc[s][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], b[ks][n], acc[s][n], 0, 0, 0);
-                }
-              }
-              if (ks + 1 < KC / 4) {
-#pragma unroll
-                for (int s = 0; s < MR; ++s) a_cur[s] = a_nx[s];
-              }
-            }
-            if (FAST || have_n) load_b(wnext, kb, c_n, ksteps_next, ks, b[ks]);
-          }
-        } else if constexpr (PFD == 1) {
+        if constexpr (PFD == 1) {
           float a_cur[MR];
 #pragma unroll
           for (int s = 0; s < MR; ++s) a_cur[s] = a_base[s * 16 * SA];
@@ -436,15 +434,30 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
         }
       }
       ++trace_steps;
-      if (!have_n) break;
-      // ---- hand over to the next step
-      store_a(As + (buf ^ 1) * (TM_ * SA), sm_n);
-      k_c = k_n;
-      c_c = c_n;
-      sm_c = sm_n;
-      advance();
+      if (!have_x) return false;
+      // ---- hand over to step x
+      store_a(r_store, As + (buf ^ 1) * (TM_ * SA), sm_x);
+      k_c = k_x;
+      c_c = c_x;
+      sm_c = sm_x;
+      if (GDEPTH == 1) advance();
+      k_x = k_n;
+      c_x = c_n;
+      sm_x = sm_n;
+      have_x = have_n;
+      if (GDEPTH == 2 && have_n) advance();
       __syncthreads();
       buf ^= 1;
+      return true;
+    };
+    if constexpr (GDEPTH == 1) {
+      while (step(ra0, ra0)) {
+      }
+    } else {
+      for (;;) {
+        if (!step(ra0, ra1)) break;
+        if (!step(ra1, ra0)) break;
+      }
     }
   }
 
