@@ -417,6 +417,8 @@ def main():
                     help="frames fused into one sparse tensor per step (batch column); 1 = the headline workload")
     ap.add_argument("--batched-frames", type=int, default=4,
                     help="secondary measurement: this many frames per step in one sparse tensor (0/1 = skip)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="headline measurement only: no batched configuration, no HBM-bound-layer block (PMC passes)")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="CPU rehearsal of the N-rank launch: rendezvous (gloo), frame sharding, the one all_gather and "
                          "the JSON line, without touching a GPU (tests/test_dist_cpu.py)")
@@ -503,7 +505,7 @@ def main():
     # ---- secondary, separately named configuration: B frames fused into one sparse tensor per step (batch column,
     #      data/alivev2.py:358-383) through the same pipeline; the headline above stays one frame per step
     batched = None
-    if args.batched_frames > 1 and args.frames_per_step == 1:
+    if args.batched_frames > 1 and args.frames_per_step == 1 and not args.no_extras:
         bsteps = max(4, args.steps // args.batched_frames)
         with torch.no_grad():
             bframes = [make_frame(rank + world * i, device, batch=args.batched_frames) for i in range(2)]
@@ -523,7 +525,7 @@ def main():
                    "frames_per_step": args.batched_frames, "steps": bsteps, "ms_per_step": round(tb / bsteps * 1e3, 3),
                    "value_this_rank": round(bsteps * args.batched_frames / tb, 3), "unit": "frames/s"}
         _log(f"batched x{args.batched_frames}: {batched['value_this_rank']} frames/s on this rank")
-    hbm_layers = hbm_bound_layers(model, device) if rank == 0 else None
+    hbm_layers = hbm_bound_layers(model, device) if (rank == 0 and not args.no_extras) else None
 
     # the run's ONE collective: all_gather of a small per-rank record (RCCL over xGMI when world > 1)
     from mrcc_amd.app.sharding import gather_metrics
@@ -591,7 +593,8 @@ def main():
             "roofline": roofline,
             "kernels_warmup": kernels,
         }
-        line["hbm_bound_layers"] = hbm_layers
+        if hbm_layers is not None:
+            line["hbm_bound_layers"] = hbm_layers
         if batched is not None:
             line["batched"] = batched
         if not args.no_cpu_baseline:

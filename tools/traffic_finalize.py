@@ -1,4 +1,5 @@
-"""gpurun_out/traffic/traffic_raw.json (tools/pmc_traffic.sh) -> profiles/r01_traffic.json.
+"""gpurun_out/traffic/traffic_raw.json (tools/pmc_traffic.sh) -> profiles/<round>_traffic.json.
+    python tools/traffic_finalize.py [raw.json] [round tag, e.g. r02] [commit the counters were collected at]
 
 FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE under-reports this kernel's row gathers, so both are scaled by the factors
 measured on the known-traffic launch (tools/traffic_calib.py), as the MI355X guide's HBM/rocprofv3 section prescribes.
@@ -46,5 +47,8 @@ for name, b in raw["bench"].items():
 for k, (n, r, w) in sorted(acc.items()):
     out["kernels"][k] = {"launches": n, "read_GB_per_launch": round(r / n / 1e9, 4),
                          "write_GB_per_launch": round(w / n / 1e9, 4), "traffic_GB_per_launch": round((r + w) / n / 1e9, 4)}
-json.dump(out, open(os.path.join(ROOT, "profiles", "r01_traffic.json"), "w"), indent=1)
+tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
+out["commit"] = sys.argv[3] if len(sys.argv) > 3 else "unknown"
+out["source"] = out["source"].replace("bench.py --steps", "bench.py --no-cpu-baseline --no-extras --steps")
+json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
