@@ -48,15 +48,17 @@ __global__ __launch_bounds__(UB) void unique_count_kernel(const uint64_t* __rest
   }
 }
 
-// single block: exclusive scan of block_counts in place, total to *total
-__global__ __launch_bounds__(1024) void unique_scan_kernel(int32_t* __restrict__ block_counts, int nblocks,
-                                                            int32_t* __restrict__ total) {
-  __shared__ int wave_sum[16];
+// single block: exclusive scan of block_counts in place, total to *total.  256 threads, so that the workgroup fits into
+// the slot of any finishing convolution workgroup (a 1024-thread workgroup needs a whole drained CU)
+constexpr int SCAN_T = 256;
+__global__ __launch_bounds__(SCAN_T) void unique_scan_kernel(int32_t* __restrict__ block_counts, int nblocks,
+                                                              int32_t* __restrict__ total) {
+  __shared__ int wave_sum[SCAN_T / 64];
   __shared__ int carry_s;
   int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
-  for (int base = 0; base < nblocks; base += 1024) {
+  for (int base = 0; base < nblocks; base += SCAN_T) {
     int i = base + threadIdx.x;
     int v = (i < nblocks) ? block_counts[i] : 0;
     // inclusive scan within the wave
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(1024) void unique_scan_kernel(int32_t* __restrict__
     int carry = carry_s;
     if (i < nblocks) block_counts[i] = carry + woff + x - v;
     __syncthreads();
-    if (threadIdx.x == 1023) carry_s = carry + woff + x;
+    if (threadIdx.x == SCAN_T - 1) carry_s = carry + woff + x;
     __syncthreads();
   }
   if (threadIdx.x == 0) *total = carry_s;
@@ -102,7 +104,7 @@ int launch_unique_sorted(const uint64_t* sorted_keys, int64_t n, uint64_t keep_m
                          int32_t* block_counts, int32_t* total, hipStream_t stream) {
   int nb = (int)unique_sorted_blocks(n);
   hipLaunchKernelGGL(unique_count_kernel, dim3(nb), dim3(UB), 0, stream, sorted_keys, n, keep_mask, block_counts);
-  hipLaunchKernelGGL(unique_scan_kernel, dim3(1), dim3(1024), 0, stream, block_counts, nb, total);
+  hipLaunchKernelGGL(unique_scan_kernel, dim3(1), dim3(SCAN_T), 0, stream, block_counts, nb, total);
   hipLaunchKernelGGL(unique_rank_kernel, dim3(nb), dim3(UB), 0, stream, sorted_keys, n, keep_mask, block_counts, rank);
   SV_LAUNCH_CHECK();
   return SV_OK;

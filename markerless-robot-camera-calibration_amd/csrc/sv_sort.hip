@@ -9,8 +9,8 @@
 // order (stable), which is what makes LSD passes compose and what makes `order` = "point indices sorted by (key,
 // original index)" exactly what the oracle's stable argsort gives.
 //
-//   n <= SMALL_MAX : ONE launch of one 1024-thread workgroup runs every pass (ping-pong through global memory, the
-//                    workgroup barrier orders the passes) - the small pyramid levels and every tile-order sort.
+//   n <= SMALL_MAX : ONE launch of one 256-thread workgroup runs every pass, tile by tile (ping-pong through global
+//                    memory, the workgroup barrier orders the passes) - the small pyramid levels and the tile orders.
 //   otherwise      : per pass   radix_hist (per-tile digit histogram, digit-major matrix)
 //                               radix_scan (one workgroup per digit: exclusive scan over the tiles, digit total)
 //                               radix_scatter (digit bases from the totals, ranks as above, scatter)
@@ -21,8 +21,7 @@ namespace sv {
 constexpr int RS_MAX_BITS = 9;
 constexpr int RS_MAX_BINS = 1 << RS_MAX_BITS;
 constexpr int RS_THREADS = 256, RS_ITEMS = 8, RS_TILE = RS_THREADS * RS_ITEMS;  // multi-workgroup path
-constexpr int RS_SMALL_THREADS = 1024, RS_SMALL_ITEMS = 8;
-constexpr int64_t RS_SMALL_MAX = (int64_t)RS_SMALL_THREADS * RS_SMALL_ITEMS;
+constexpr int64_t RS_SMALL_MAX = 4 * RS_TILE;  // up to 8192 pairs go through the one-launch single-workgroup sort
 
 // Ranks of one tile.  Wave w owns keys [tile_base + w*64*ITEMS, +64*ITEMS), visited in ITEMS rounds of 64 consecutive keys.
 // On return: rank[r] = number of keys with the same digit that precede key r inside the wave's segment, and (after the
@@ -188,50 +187,63 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const KeyT* _
 }
 
 // ---- single-workgroup path: every pass in one launch ----------------------------------------------------------------
+// 256 threads (four waves): the workgroup fits into the slot any finishing convolution workgroup leaves behind.  (A
+// 1024-thread form needs a whole drained CU; beside the chip-filling convolutions of the neighbour frame it waited for
+// one ~350 us per call, profiles/r02: the prep stream's sorts are latency, not throughput.)
 template <typename KeyT>
-__global__ __launch_bounds__(RS_SMALL_THREADS) void radix_sort_small_kernel(const KeyT* __restrict__ keys_in,
-                                                                            const int32_t* __restrict__ vals_in, int n,
-                                                                            int begin_bit, int end_bit,
-                                                                            KeyT* __restrict__ kbuf0, int32_t* __restrict__ vbuf0,
-                                                                            KeyT* __restrict__ kbuf1, int32_t* __restrict__ vbuf1,
-                                                                            int first_dst) {
-  constexpr int NW = RS_SMALL_THREADS / 64;
-  __shared__ uint32_t wcnt[NW * RS_MAX_BINS];  // 32 KB
-  __shared__ uint32_t gofs[RS_MAX_BINS];
+__global__ __launch_bounds__(RS_THREADS) void radix_sort_small_kernel(const KeyT* __restrict__ keys_in,
+                                                                      const int32_t* __restrict__ vals_in, int n,
+                                                                      int begin_bit, int end_bit, KeyT* __restrict__ kbuf0,
+                                                                      int32_t* __restrict__ vbuf0, KeyT* __restrict__ kbuf1,
+                                                                      int32_t* __restrict__ vbuf1, int first_dst) {
+  constexpr int NW = RS_THREADS / 64;
+  __shared__ uint32_t wcnt[NW * RS_MAX_BINS];
+  __shared__ uint32_t base[RS_MAX_BINS];  // running start of every digit's output range
+  __shared__ uint32_t tcnt[RS_MAX_BINS];  // digit counts of the current tile
   const KeyT* kin = keys_in;
   const int32_t* vin = vals_in;  // null = iota
   int dst = first_dst;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (int shift = begin_bit; shift < end_bit;) {
     const int left = end_bit - shift;
-    // equal-ish digits: ceil(left / passes_left) bits, at most RS_MAX_BITS
     const int passes_left = (left + RS_MAX_BITS - 1) / RS_MAX_BITS;
-    const int bits = (left + passes_left - 1) / passes_left;
+    const int bits = (left + passes_left - 1) / passes_left;  // equal-ish digits, at most RS_MAX_BITS bits
     const int bins = 1 << bits;
+    const uint32_t dmask = (uint32_t)bins - 1u;
     KeyT* kout = dst ? kbuf1 : kbuf0;
     int32_t* vout = dst ? vbuf1 : vbuf0;
-    for (int i = threadIdx.x; i < NW * bins; i += RS_SMALL_THREADS) wcnt[i] = 0;
+    // digit histogram of the whole input -> digit bases
+    for (int d = threadIdx.x; d < bins; d += RS_THREADS) base[d] = 0;
     __syncthreads();
-    KeyT key[RS_SMALL_ITEMS];
-    uint32_t rank[RS_SMALL_ITEMS], dig[RS_SMALL_ITEMS];
-    rank_tile<KeyT, RS_SMALL_ITEMS>(kin, 0, n, shift, bits, wcnt, key, rank, dig);
-    int32_t val[RS_SMALL_ITEMS];
+    for (int i = threadIdx.x; i < n; i += RS_THREADS) atomicAdd(&base[(uint32_t)(kin[i] >> shift) & dmask], 1u);
+    exclusive_scan_bins(base, bins);
+    // tiles in input order: stable ranks inside the tile, then advance the digit bases by the tile's counts
+    for (int tile = 0; tile < n; tile += RS_TILE) {
+      for (int i = threadIdx.x; i < NW * bins; i += RS_THREADS) wcnt[i] = 0;
+      __syncthreads();
+      KeyT key[RS_ITEMS];
+      uint32_t rank[RS_ITEMS], dig[RS_ITEMS];
+      rank_tile<KeyT, RS_ITEMS>(kin, tile, n, shift, bits, wcnt, key, rank, dig);
+      int32_t val[RS_ITEMS];
 #pragma unroll
-    for (int r = 0; r < RS_SMALL_ITEMS; ++r) {
-      const int i = w * (64 * RS_SMALL_ITEMS) + r * 64 + lane;
-      val[r] = (i < n) ? (vin ? vin[i] : i) : 0;
-    }
-    __syncthreads();
-    prefix_over_waves<NW>(wcnt, gofs, bins);
-    exclusive_scan_bins(gofs, bins);
+      for (int r = 0; r < RS_ITEMS; ++r) {
+        const int i = tile + w * (64 * RS_ITEMS) + r * 64 + lane;
+        val[r] = (i < n) ? (vin ? vin[i] : i) : 0;
+      }
+      __syncthreads();
+      prefix_over_waves<NW>(wcnt, tcnt, bins);
+      __syncthreads();
 #pragma unroll
-    for (int r = 0; r < RS_SMALL_ITEMS; ++r) {
-      if (dig[r] == 0xffffffffu) continue;
-      const uint32_t pos = gofs[dig[r]] + wcnt[w * bins + dig[r]] + rank[r];
-      kout[pos] = key[r];
-      vout[pos] = val[r];
+      for (int r = 0; r < RS_ITEMS; ++r) {
+        if (dig[r] == 0xffffffffu) continue;
+        const uint32_t pos = base[dig[r]] + wcnt[w * bins + dig[r]] + rank[r];
+        kout[pos] = key[r];
+        vout[pos] = val[r];
+      }
+      __syncthreads();
+      for (int d = threadIdx.x; d < bins; d += RS_THREADS) base[d] += tcnt[d];
+      __syncthreads();  // also the workgroup-scope release/acquire that lets the next pass read what this one wrote
     }
-    __syncthreads();  // workgroup-scope release/acquire: the next pass reads what this one wrote
     kin = kout;
     vin = vout;
     dst ^= 1;
@@ -269,7 +281,7 @@ int radix_sort_pairs(const KeyT* keys_in, const int32_t* vals_in, KeyT* keys_out
   // the last pass must write keys_out / vals_out: buffer 1 = out, buffer 0 = temp, alternate backwards from the end
   int dst = (passes % 2 == 1) ? 1 : 0;
   if (n <= RS_SMALL_MAX) {
-    hipLaunchKernelGGL(radix_sort_small_kernel<KeyT>, dim3(1), dim3(RS_SMALL_THREADS), 0, stream, keys_in, vals_in, (int)n,
+    hipLaunchKernelGGL(radix_sort_small_kernel<KeyT>, dim3(1), dim3(RS_THREADS), 0, stream, keys_in, vals_in, (int)n,
                        begin_bit, end_bit, ktmp, vtmp, keys_out, vals_out, dst);
     SV_LAUNCH_CHECK();
     return SV_OK;
