@@ -51,9 +51,14 @@ struct ConvParams {
   int ntiles;
   int ny;
   unsigned long long* trace;  // SV_CONV_TRACE experiments: per-workgroup {start, end, hw id, steps}; null otherwise
+  int main_blocks;            // dual-body launches: workgroups [0, main_blocks) run the main tile shape over the plan tiles
+  int main_tiles128;          //   tile_order[0, main_tiles128), the rest the tail shape over tile_order[main_tiles128, ..)
 };
 
-constexpr int PLAN_TILE = SV_TILE_ROWS;  // plans (perm / nbr_s / submask) are laid out in 128-row tiles
+constexpr int PLAN_TILE = SV_TILE_ROWS;
+#ifndef SV_CONV_TAIL_DEFAULT
+#define SV_CONV_TAIL_DEFAULT 0.15  // share of the plan tiles (the cheapest) that chip-filling launches run as half-height tiles
+#endif  // plans (perm / nbr_s / submask) are laid out in 128-row tiles
 // input channels per pipeline step: short tiles (used on small pyramid levels, where a launch is bound by the latency
 // of a tile's sequential step chain) take wider chunks, i.e. fewer barriers / gather round trips per tile
 constexpr int chunk_for(int tm, int waves_n) {
@@ -116,8 +121,10 @@ struct ConvCfg {
 //   variant keeps per-lane guards (odd channel counts such as Cin = 3 or Cout = 3).
 // RING: A operands are read PFD k-steps ahead of the matrix ops through a register ring (launches of few workgroups).
 // FULL: no partial chunk in the layer -> compile-time trip count and plain weight addressing in the matrix loop.
+// conv_tile_body: one workgroup's tile.  bidx = index of the workgroup inside its body's range of the grid, tile_base =
+// first entry of tile_order (plan tiles of 128 rows, longest first) that range starts at.
 template <int TM_, int WAVES_N, int NT, bool FAST, int CPO = 0, bool RING = false, bool FULL = false>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
+__device__ __forceinline__ void conv_tile_body(const ConvParams& p, const int bidx, const int tile_base) {
   static_assert(FAST || !FULL, "FULL is a refinement of the FAST form");
   using Cfg = ConvCfg<TM_, WAVES_N, NT, CPO>;
   constexpr int MR = Cfg::MR, TN = Cfg::TN, A_F4 = Cfg::A_F4, KC = Cfg::KC, SA = Cfg::SA, GK = Cfg::GK;
@@ -138,13 +145,13 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
   // 1-D grid, longest tiles first (list scheduling): plan tiles are visited in the plan's tile_order (sorted by active
   // (offset, sub-tile) slots, descending); without one, in reverse plan order (rows are sorted by neighbour key, so
   // the tiles with the most neighbour offsets sit at the end).
-  const int ny = p.ny;
+  const int ny = (p.Cout + TN - 1) / TN;
   constexpr int SUB_PER_PLAN_TILE = PLAN_TILE / TM_;
-  const int t_lin = (int)(blockIdx.x / ny);
-  const int t128 = t_lin / SUB_PER_PLAN_TILE;
-  const int p128 = p.tile_order ? p.tile_order[t128] : (p.ntiles / SUB_PER_PLAN_TILE - 1 - t128);
+  const int t_lin = bidx / ny;
+  const int t128 = tile_base + t_lin / SUB_PER_PLAN_TILE;
+  const int p128 = p.tile_order ? p.tile_order[t128] : ((int)(p.Vpad / PLAN_TILE) - 1 - t128);
   const int tile = p128 * SUB_PER_PLAN_TILE + (t_lin % SUB_PER_PLAN_TILE);
-  const int n0 = (int)(blockIdx.x % ny) * TN;
+  const int n0 = (bidx % ny) * TN;
   const int64_t row0 = (int64_t)tile * TM_;
   const int li = lane & 15, lq = lane >> 4;
   const int K = p.K, Cin = p.Cin, Cout = p.Cout;
@@ -518,6 +525,25 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
   }
 }
 
+template <int TM_, int WAVES_N, int NT, bool FAST, int CPO = 0, bool RING = false, bool FULL = false>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
+  conv_tile_body<TM_, WAVES_N, NT, FAST, CPO, RING, FULL>(p, (int)blockIdx.x, 0);
+}
+
+// Dual-body launch for chip-filling layers: the hardware hands out workgroups in blockIdx order, so the grid is the plan
+// tiles in longest-first order as TM_-row tiles followed by the CHEAPEST plan tiles as TAIL_TM-row tiles.  A launch ends
+// with every CU's residency decaying from 4 workgroups to 0 over about the duration of its last (cheapest) tiles; with
+// half-height tiles at the end that decay is half as long (tools/wg_trace.py: ~22 % of a level-0 launch, i.e. ~11 % of
+// its slot-time idle).  Everything else about a tile - offsets visited, the (k, c) order of every output element's fma
+// chain, hence every result bit - is independent of the tile height.
+template <int TM_, int TAIL_TM, int WAVES_N, int NT, bool FAST>
+__global__ __launch_bounds__(256) void conv_fwd_dual_kernel(ConvParams p) {
+  if ((int)blockIdx.x < p.main_blocks)
+    conv_tile_body<TM_, WAVES_N, NT, FAST>(p, (int)blockIdx.x, 0);
+  else
+    conv_tile_body<TAIL_TM, WAVES_N, NT, FAST>(p, (int)blockIdx.x - p.main_blocks, p.main_tiles128);
+}
+
 // ---- narrow-output dense layer (K = 1, identity rows, Cout <= 4: the last Linear of the classification heads,
 //      model/robotnet_segmentation.py:43-48).  1.5 flop per byte: an HBM stream, not a matrix problem - on the MFMA
 //      tiles 13 of 16 output columns would be padding and the step chain (gather -> LDS -> barrier) is latency-bound.
@@ -753,6 +779,43 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
   return SV_OK;
 }
 
+// dual-body launch (conv_fwd_dual_kernel): TM_-row tiles for the expensive plan tiles, TAIL_TM-row tiles for the cheapest
+// `tail_fraction` of them.  Returns SV_ERR_INVALID without launching when the layer does not qualify.
+template <int TM_, int TAIL_TM, int WAVES_N, int NT>
+static int launch_conv_dual(const ConvParams& p, hipStream_t stream, double tail_fraction) {
+  using Main = ConvCfg<TM_, WAVES_N, NT, 0>;
+  using Tail = ConvCfg<TAIL_TM, WAVES_N, NT, 0>;
+  const bool fast = p.vec_a && (p.Cout % Main::TN == 0);
+  const int n128 = (int)(p.Vpad / PLAN_TILE);
+  const int tail128 = (int)(n128 * tail_fraction);
+  if (!fast || !p.tile_order || tail128 < 1 || tail128 >= n128) return SV_ERR_INVALID;
+  ConvParams q = p;
+  q.ny = p.Cout / Main::TN;
+  q.main_tiles128 = n128 - tail128;
+  q.main_blocks = q.main_tiles128 * (PLAN_TILE / TM_) * q.ny;
+  q.ntiles = (int)(p.Vpad / TM_);
+  const unsigned grid = (unsigned)(q.main_blocks + tail128 * (PLAN_TILE / TAIL_TM) * q.ny);
+  const size_t lds = Main::lds_bytes(p.K) > Tail::lds_bytes(p.K) ? Main::lds_bytes(p.K) : Tail::lds_bytes(p.K);
+  static const char* trace_path = getenv("SV_CONV_TRACE");
+  q.trace = nullptr;
+  if (trace_path) SV_HIP(hipMalloc((void**)&q.trace, (size_t)grid * 4 * sizeof(unsigned long long)));
+  hipLaunchKernelGGL((conv_fwd_dual_kernel<TM_, TAIL_TM, WAVES_N, NT, true>), dim3(grid), dim3(256), lds, stream, q);
+  SV_LAUNCH_CHECK();
+  if (q.trace) {
+    std::vector<unsigned long long> host((size_t)grid * 4);
+    SV_HIP(hipStreamSynchronize(stream));
+    SV_HIP(hipMemcpy(host.data(), q.trace, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    SV_HIP(hipFree(q.trace));
+    if (FILE* f = fopen(trace_path, "ab")) {
+      const long long hdr[8] = {0x5356545243ll, (long long)grid, TM_, WAVES_N, NT, q.ny, p.K, p.Cin};
+      fwrite(hdr, sizeof(hdr), 1, f);
+      fwrite(host.data(), sizeof(unsigned long long), host.size(), f);
+      fclose(f);
+    }
+  }
+  return SV_OK;
+}
+
 // ---- instance selection ------------------------------------------------------------------------------------------
 // A tile is processed sequentially (K * Cin / KC steps) and streams K*Cin*TN weights + its gathered rows through one CU,
 // so the choice trades per-CU cache bandwidth (tall tiles, few column slices) against parallelism / tail (many tiles).
@@ -849,8 +912,16 @@ static int select_and_launch(const ConvParams& p, hipStream_t stream) {
     if (sscanf(f, "%d,%d,%d,%d", &c.tm, &c.wn, &c.nt, &c.cpo) >= 3) return launch_candidate(c, p, stream);
   }
   static const double want_scale = getenv("SV_CONV_WANT_SCALE") ? atof(getenv("SV_CONV_WANT_SCALE")) : 1.0;
+  // chip-filling 384-wide layers: 64-row tiles, and 32-row tiles for the cheapest plan tiles at the end of the grid
+  static const double tail_fraction = getenv("SV_CONV_TAIL") ? atof(getenv("SV_CONV_TAIL")) : SV_CONV_TAIL_DEFAULT;
   for (int i = 0; i < n; ++i)
-    if ((double)candidate_wgs(list[i], p) >= want_scale * (double)list[i].want) return launch_candidate(list[i], p, stream);
+    if ((double)candidate_wgs(list[i], p) >= want_scale * (double)list[i].want) {
+      const Candidate& c = list[i];
+      if (c.tm == 64 && c.wn == 4 && c.nt == 3 && c.cpo == 0 && tail_fraction > 0.0 &&
+          launch_conv_dual<64, 32, 4, 3>(p, stream, tail_fraction) == SV_OK)
+        return SV_OK;
+      return launch_candidate(c, p, stream);
+    }
   return launch_candidate(list[n - 1], p, stream);
 }
 
@@ -882,6 +953,8 @@ extern "C" int sv_conv_fwd(const float* in, int64_t in_ld, int Cin, const float*
   p.ntiles = 0;
   p.ny = 0;
   p.trace = nullptr;
+  p.main_blocks = 0;
+  p.main_tiles128 = 0;
   static const bool no_first = getenv("SV_CONV_NO_FIRST") != nullptr;  // experiments only
   if (has_plan && K > 1 && K <= 27 && Cin == 3 && Cout == 32 && !no_first) return launch_conv_first_layer(p, stream);
   static const bool no_narrow = getenv("SV_CONV_NO_NARROW") != nullptr;  // experiments only

@@ -21,6 +21,9 @@ _CANDIDATES = {
 }
 
 
+CONV_TAIL_FRACTION = 0.15  # SV_CONV_TAIL_DEFAULT of csrc/sv_conv.hip
+
+
 _FUSED = {  # (Cin, Cout) -> candidates of the fused-offset form (thin layers, K > 1)
     (32, 32): [(64, 2, 1, 3000), (32, 2, 1, 0)],
     (32, 64): [(32, 4, 1, 1500), (16, 4, 1, 0)],
@@ -61,6 +64,9 @@ def conv_kernel_config(Cout, Vpad, Cin=None, K=1):
     for tm, wn, nt, want in cands:
         tn = wn * nt * 16
         if (Vpad // tm) * ((Cout + tn - 1) // tn) >= want:
+            if ((tm, wn, nt) == (64, 4, 3) and fused is None and K > 1 and Cin is not None and Cin % 4 == 0
+                    and Cout % tn == 0 and int((Vpad // 128) * CONV_TAIL_FRACTION) >= 1):
+                return "conv_fwd_dual_kernel<64, 32, 4, 3>"  # chip-filling layer: half-height tiles at the end of the grid
             return f"conv_fwd_kernel<{tm}, {wn}, {nt}{suffix}"
     tm, wn, nt, _ = cands[-1]
     return f"conv_fwd_kernel<{tm}, {wn}, {nt}{suffix}"

@@ -1,9 +1,9 @@
 """BASELINE.json configurations at their FULL sizes against the oracle.
 
   Cfg-2  200k points / 2 cm through the real RobotNetSegmentation(MinkUNet18D): logits bit-exact, labels exact — the
-         only place where conv_fwd_kernel<64,4,3> / <64,4,2> walk 12-13 channel chunks per offset (Cin 384 / 416) and
-         where <128,4,2> runs at all, so those instances meet the oracle here; plus direct launches that FORCE each
-         of them onto multi-chunk layers (SV_CONV_FORCE).
+         only place where the chip-filling instances (conv_fwd_dual_kernel<64,32,4,3>, <64,4,3>, <64,4,2>) walk 12-13
+         channel chunks per offset (Cin 384 / 416) and where <128,4,2> runs at all, so those instances meet the oracle
+         here; plus direct launches that FORCE each tile shape onto multi-chunk layers (SV_CONV_FORCE).
   Cfg-5  500k points / 1 cm (305k voxels) through the same head: every distinct layer shape of the forward pass is
          compared with the oracle on a random row subset (the oracle computes single output rows from the GPU's own
          input tensor, so the check is bit-exact and costs seconds), labels = argmax, duplicate-frame equality.
@@ -113,7 +113,8 @@ def test_cfg2_full_network_bit_exact(gpu, oracle, cfg2):
         out = model(x)
         label, conf = out.slice_argmax(field)
     used = set(rec.names)
-    for inst in ("conv_fwd_kernel<64, 4, 3>", "conv_fwd_kernel<64, 4, 2>", "conv_fwd_kernel<128, 4, 2>",
+    for inst in ("conv_fwd_dual_kernel<64, 32, 4, 3>", "conv_fwd_kernel<64, 4, 3>", "conv_fwd_kernel<64, 4, 2>",
+                 "conv_fwd_kernel<16, 4, 3>", "conv_fwd_kernel<128, 4, 2>",
                  "conv_first_layer_kernel<3, 32>", "linear_narrow_kernel<3>"):
         assert inst in used, (inst, sorted(used))
     sd = {k: v.cpu() for k, v in model.state_dict().items()}

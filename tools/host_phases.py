@@ -9,7 +9,7 @@ dev = torch.device("cuda:0")
 model = bench.build_model(dev)
 frames = [bench.make_frame(i, dev) for i in range(4)]
 for prio in (0, -1):
-    pipe = FramePipeline(dev, levels=4)
+    pipe = FramePipeline(dev, levels=4, compute_streams=2)
     if prio:
         pipe.prep_stream = torch.cuda.Stream(device=dev, priority=prio)
     def unet(x, field):
@@ -31,7 +31,7 @@ for prio in (0, -1):
         tot = time.perf_counter() - t0
     print(f"prio={prio}: per frame wall {tot / n * 1e3:.2f} ms; host run-enqueue {tr / n * 1e3:.2f} ms; host prepare {tp / n * 1e3:.2f} ms")
 # prepare alone on an idle GPU
-pipe = FramePipeline(dev, levels=4)
+pipe = FramePipeline(dev, levels=4, compute_streams=2)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for i in range(5):

@@ -16,7 +16,7 @@ import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 for f in glob.glob("$OUT/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "conv_fwd_kernel" not in r["Kernel_Name"]: continue
+        if "conv_fwd_kernel" not in r["Kernel_Name"] and "conv_fwd_dual_kernel" not in r["Kernel_Name"]: continue
         agg[r["Kernel_Name"][:40]][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(r["Kernel_Name"][:40], r["Counter_Name"])] += 1
 for k, d in agg.items():
     print(k)

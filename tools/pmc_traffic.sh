@@ -12,7 +12,7 @@ def per_kernel(prefix, counter):
     acc = collections.defaultdict(list)
     for f in glob.glob(f"$OUT/{prefix}_{counter}/*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == counter and ("conv_fwd_kernel" in r["Kernel_Name"] or "linear_narrow_kernel" in r["Kernel_Name"]):
+            if r["Counter_Name"] == counter and ("conv_fwd_kernel" in r["Kernel_Name"] or "conv_fwd_dual_kernel" in r["Kernel_Name"] or "linear_narrow_kernel" in r["Kernel_Name"]):
                 acc[r["Kernel_Name"].split("(")[0].replace("void sv::", "")].append(float(r["Counter_Value"]))
     return acc
 V = 2_000_000

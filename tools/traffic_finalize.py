@@ -17,6 +17,9 @@ def fold(name):
     m = re.search(r"linear_narrow_kernel<(\d+)", name)
     if m:
         return f"linear_narrow_kernel<{m.group(1)}>"
+    m = re.search(r"conv_fwd_dual_kernel<(\d+), (\d+), (\d+), (\d+)", name)
+    if m:
+        return f"conv_fwd_dual_kernel<{m.group(1)}, {m.group(2)}, {m.group(3)}, {m.group(4)}>"
     m = re.search(r"conv_fwd_kernel<([^>]*)>", name)
     a = [x.strip() for x in m.group(1).split(",")]
     cpo = int(a[4]) if len(a) > 4 else 0
