@@ -156,6 +156,22 @@ int sv_affine_act(const float* in, int64_t in_ld, int C, int64_t V, const float*
                   sv_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * A11  pre-voxelisation transforms on device rows
+ *   (replace utils/preprocess.py:8-11 center_at_origin, :14-17 base_at_origin, :20-37 normalize_colors,
+ *    :40-56 normalize_points; callers app/inference_engine.py:396-404,440-444,470-488)
+ * ------------------------------------------------------------------------------------------- */
+/* Column statistics of x[N][C], C <= 4: col_min[C], col_max[C] (exact), col_sum[C] (float64, deterministic order) and,
+ * when max_row_norm is given, max over rows of the float32 norm of (row - sub) in numpy's order
+ * sqrt(((x0-s0)^2 + (x1-s1)^2) + (x2-s2)^2).  workspace: sv_col_stats_workspace_bytes(N). */
+size_t sv_col_stats_workspace_bytes(int64_t N);
+int sv_col_stats(const float* x, int64_t ld, int64_t N, int C, const float* sub, void* workspace, size_t workspace_bytes,
+                 float* col_min, float* col_max, double* col_sum, float* max_row_norm, sv_stream_t stream);
+/* out[r][c] = (x[r][c] - sub[c]) / div[c] + add[c]; a null sub / div / add skips that operation (IEEE float32 operations
+ * in this order: `points - offset` and `rgb / 255` round exactly as the reference's numpy expressions). */
+int sv_center_scale(const float* x, int64_t ld, int64_t N, int C, const float* sub, const float* div, const float* add,
+                    float* out, int64_t out_ld, sv_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * A6/A7  pooling, slice, argmax
  *   (replace ME.MinkowskiGlobalMaxPooling/AvgPooling model/robotnet.py:43, robotnet_encode.py:41;
  *    SparseTensor.slice app/inference_engine.py:417,551; utils/output.py:67-73)

@@ -47,6 +47,9 @@ SIGNATURES = {
          _P, c_int64, _P],
     ),
     "sv_affine_act": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, _P, c_int64, c_int, c_float, _P, c_int64, _P]),
+    "sv_col_stats_workspace_bytes": (c_size_t, [c_int64]),
+    "sv_col_stats": (c_int, [_P, c_int64, c_int64, c_int, _P, _P, c_size_t, _P, _P, _P, _P, _P]),
+    "sv_center_scale": (c_int, [_P, c_int64, c_int64, c_int, _P, _P, _P, _P, c_int64, _P]),
     "sv_batch_offsets": (c_int, [_P, c_int64, c_int, _P, _P]),
     "sv_global_pool": (c_int, [_P, c_int64, c_int, _P, c_int, c_int, _P, _P]),
     "sv_slice_rows": (c_int, [_P, c_int64, c_int, _P, c_int64, _P, _P]),

@@ -102,11 +102,143 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
   out[v * out_ld + c] = y;
 }
 
+// ---- A11 preprocessing (utils/preprocess.py:8-56) on device rows -----------------------------------------------------
+// column statistics of x[N][C] (C <= 4): per column min, max (exact), sum (float64), and - when `sub` is given - the
+// maximum over rows of the float32 norm sqrt(((x0-s0)^2 + (x1-s1)^2) + (x2-s2)^2), numpy's np.linalg.norm order.
+// Stage 1: every workgroup reduces a contiguous slab of rows to one record; stage 2: one workgroup reduces the records
+// in slab order (deterministic: no atomics).
+constexpr int STAT_REC = 16;  // doubles per record: min[4], max[4], sum[4], normmax, pad
+__global__ __launch_bounds__(256) void col_stats_partial_kernel(const float* __restrict__ x, int64_t ld, int64_t N, int C,
+                                                                 const float* __restrict__ sub, int64_t rows_per_block,
+                                                                 double* __restrict__ rec) {
+  __shared__ double sh[256 / 64][STAT_REC];
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(N, r0 + rows_per_block);
+  float mn[4], mx[4];
+  double sm[4];
+  float nmax = 0.0f;
+  for (int c = 0; c < 4; ++c) {
+    mn[c] = INFINITY;
+    mx[c] = -INFINITY;
+    sm[c] = 0.0;
+  }
+  for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < C; ++c) {
+      v[c] = x[r * ld + c];
+      mn[c] = fminf(mn[c], v[c]);
+      mx[c] = fmaxf(mx[c], v[c]);
+      sm[c] += (double)v[c];
+    }
+    if (sub) {
+      const float a = v[0] - sub[0], b = v[1] - sub[1], d = (C > 2) ? v[2] - sub[2] : 0.0f;
+      nmax = fmaxf(nmax, sqrtf((a * a + b * b) + d * d));
+    }
+  }
+  // wave reduction by shuffles, then across the four waves through LDS
+  for (int off = 32; off >= 1; off >>= 1) {
+    for (int c = 0; c < 4; ++c) {
+      mn[c] = fminf(mn[c], __shfl_down(mn[c], off));
+      mx[c] = fmaxf(mx[c], __shfl_down(mx[c], off));
+      sm[c] += __shfl_down(sm[c], off);
+    }
+    nmax = fmaxf(nmax, __shfl_down(nmax, off));
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) {
+    for (int c = 0; c < 4; ++c) {
+      sh[wid][c] = mn[c];
+      sh[wid][4 + c] = mx[c];
+      sh[wid][8 + c] = sm[c];
+    }
+    sh[wid][12] = nmax;
+  }
+  __syncthreads();
+  if (threadIdx.x < STAT_REC) {
+    const int j = threadIdx.x;
+    double a = sh[0][j];
+    for (int w = 1; w < 4; ++w) a = (j < 4) ? fmin(a, sh[w][j]) : ((j < 8 || j == 12) ? fmax(a, sh[w][j]) : a + sh[w][j]);
+    rec[(int64_t)blockIdx.x * STAT_REC + j] = (j > 12) ? 0.0 : a;
+  }
+}
+
+__global__ __launch_bounds__(64) void col_stats_final_kernel(const double* __restrict__ rec, int nrec, int C,
+                                                              float* __restrict__ mn, float* __restrict__ mx,
+                                                              double* __restrict__ sum, float* __restrict__ normmax) {
+  const int j = threadIdx.x;
+  if (j >= 13) return;
+  double a = rec[j];
+  for (int b = 1; b < nrec; ++b) {
+    const double v = rec[(int64_t)b * STAT_REC + j];
+    a = (j < 4) ? fmin(a, v) : ((j < 8 || j == 12) ? fmax(a, v) : a + v);
+  }
+  if (j < 4 && j < C) mn[j] = (float)a;
+  if (j >= 4 && j < 8 && j - 4 < C) mx[j - 4] = (float)a;
+  if (j >= 8 && j < 12 && j - 8 < C) sum[j - 8] = a;
+  if (j == 12 && normmax) *normmax = (float)a;
+}
+
+// out = (x - sub[c]) / div[c] + add[c]; each of the three is applied only when its pointer is given (IEEE f32 operations
+// in that order, so `points - offset` and `rgb / 255` round exactly as numpy's do)
+__global__ __launch_bounds__(256) void center_scale_kernel(const float* __restrict__ x, int64_t ld, int64_t N, int C,
+                                                            const float* __restrict__ sub, const float* __restrict__ div,
+                                                            const float* __restrict__ add, float* __restrict__ out,
+                                                            int64_t out_ld) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= N * C) return;
+  const int64_t r = t / C;
+  const int c = (int)(t - r * C);
+  float v = x[r * ld + c];
+  if (sub) v = v - sub[c];
+  if (div) v = v / div[c];
+  if (add) v = v + add[c];
+  out[r * out_ld + c] = v;
+}
+
 }  // namespace sv
 
 using namespace sv;
 
 extern "C" {
+
+size_t sv_col_stats_workspace_bytes(int64_t N) {
+  const int64_t blocks = N <= 0 ? 1 : (N + 4095) / 4096;
+  return (size_t)(blocks < 1024 ? blocks : 1024) * STAT_REC * sizeof(double) + 256;
+}
+
+int sv_col_stats(const float* x, int64_t ld, int64_t N, int C, const float* sub, void* workspace, size_t workspace_bytes,
+                 float* col_min, float* col_max, double* col_sum, float* max_row_norm, sv_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SV_CHECK_ARG(N >= 1 && C >= 1 && C <= 4 && ld >= C, "bad shape (1 <= C <= 4, N >= 1)");
+  SV_CHECK_ARG(x && workspace && col_min && col_max && col_sum, "null pointer");
+  SV_CHECK_ARG(!max_row_norm || (sub && C >= 2), "max_row_norm needs sub and at least two columns");
+  int64_t blocks = (N + 4095) / 4096;
+  if (blocks > 1024) blocks = 1024;
+  const int64_t rows_per_block = (N + blocks - 1) / blocks;
+  if (workspace_bytes < (size_t)blocks * STAT_REC * sizeof(double)) {
+    set_error("sv_col_stats: workspace too small");
+    return SV_ERR_WORKSPACE;
+  }
+  double* rec = (double*)workspace;
+  hipLaunchKernelGGL(col_stats_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, ld, N, C,
+                     max_row_norm ? sub : nullptr, rows_per_block, rec);
+  hipLaunchKernelGGL(col_stats_final_kernel, dim3(1), dim3(64), 0, stream, rec, (int)blocks, C, col_min, col_max, col_sum,
+                     max_row_norm);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+int sv_center_scale(const float* x, int64_t ld, int64_t N, int C, const float* sub, const float* div, const float* add,
+                    float* out, int64_t out_ld, sv_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SV_CHECK_ARG(N >= 0 && C >= 1 && ld >= C && out_ld >= C, "bad shape");
+  if (N == 0) return SV_OK;
+  SV_CHECK_ARG(x && out, "null pointer");
+  hipLaunchKernelGGL(center_scale_kernel, dim3((unsigned)((N * C + 255) / 256)), dim3(256), 0, stream, x, ld, N, C, sub,
+                     div, add, out, out_ld);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
 
 int sv_batch_offsets(const uint64_t* keys, int64_t V, int B, int32_t* batch_start, sv_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;

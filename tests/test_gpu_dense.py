@@ -170,3 +170,32 @@ def test_calibration_chain_vs_reference_golden(gpu, golden):
         worst = max(worst, close(T.transform_pose2pose(g["ee2cam"][b], g["ee2robot"][b]), g["pose2pose"][b]))
         worst = max(worst, close(T.get_pose_from_matrix(g["matrix"][b]), g["pose_from_matrix"][b]))
     assert worst < 1e-9, worst
+
+
+def test_preprocess_device_path_vs_reference_golden(gpu, golden):
+    """A11: utils/preprocess.py:8-56 on rows that already live in HBM (sv_col_stats + sv_center_scale) against vectors
+    produced by the reference's own functions.  center/base shifts are exact float32 operations -> bit-exact; /255 and
+    the -0.5 shift likewise; the unit-sphere normalisation sums in float64 (the reference: numpy pairwise float32) -> 1e-6."""
+    from mrcc_amd.utils import preprocess as P
+
+    g = golden("preprocess")
+    t = lambda a: torch.from_numpy(a).to(gpu)
+    c, off = P.center_at_origin(t(g["points"]))
+    assert c.is_cuda and np.array_equal(c.cpu().numpy(), g["centred"]) and np.array_equal(off.cpu().numpy(), g["offset"])
+    b, boff = P.base_at_origin(t(g["points"]))
+    assert np.array_equal(b.cpu().numpy(), g["points"] - g["points"].min(axis=0)) and np.array_equal(
+        boff.cpu().numpy(), g["points"].min(axis=0))
+    assert np.array_equal(P.normalize_colors(t(g["rgb255"])).cpu().numpy(), g["rgb255_out"])
+    assert np.array_equal(P.normalize_colors(t(g["rgb01"])).cpu().numpy(), g["rgb01_out"])
+    assert np.allclose(P.normalize_points(t(g["points"])).cpu().numpy(), g["norm_points"], atol=1e-6, rtol=0)
+    # the min-max branch (negative colour values, utils/preprocess.py:28-32) against the host mirror of the same function
+    rng = np.random.default_rng(1)
+    neg = rng.uniform(-0.3, 0.9, size=(5000, 3)).astype(np.float32)
+    assert np.allclose(P.normalize_colors(t(neg)).cpu().numpy(), P.normalize_colors(neg), atol=2e-7, rtol=0)
+    # strided view (a column slice of a wider buffer) and a large input: 2M rows reduce in 489 slabs, deterministically
+    wide = rng.normal(size=(2_000_000, 6)).astype(np.float32)
+    c1, o1 = P.center_at_origin(t(wide)[:, 1:4])
+    want_c, want_o = (lambda p: (p - (p.max(axis=0) + p.min(axis=0)) / 2, (p.max(axis=0) + p.min(axis=0)) / 2))(wide[:, 1:4])
+    assert np.array_equal(c1.cpu().numpy(), want_c) and np.array_equal(o1.cpu().numpy(), want_o)
+    c2, _ = P.center_at_origin(t(wide)[:, 1:4])
+    assert torch.equal(c1, c2)

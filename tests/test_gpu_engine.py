@@ -248,3 +248,62 @@ def test_rccl_metrics_gather_single_rank(gpu):
         assert agg["frames"] == 3 and agg["elapsed_max"] == 0.5 and agg["seed_sum"] == 7
     finally:
         dist.destroy_process_group()
+
+
+def test_engine_stages_match_the_oracle(gpu, oracle):
+    """N1: the numbers the evaluation harness reports come from InferenceEngine's stages - pin each stage to the oracle
+    on a labelled synthetic scene: segmentation labels (incl. the largest-cluster rule of app/inference_engine.py:419-433)
+    exact, the NN rotation within 1e-4 (north_star tolerance), the key-point pose and its ADD against the oracle's SVD."""
+    import mrcc_amd
+    from mrcc_amd.app.inference_engine import InferenceEngine
+    from mrcc_amd.utils import metrics as M
+    from mrcc_amd.utils import preprocess
+    from mrcc_amd.utils.config import Config
+
+    Config.reset()
+    Config().update({"INFERENCE": {"SEGMENTATION": {"scale": 50}, "ROTATION": {"scale": 100},
+                                   "KEY_POINTS": {"scale": 100, "conf_threshold": 0.0},
+                                   "ee_point_counts_threshold": 64, "SANITY": {"min_num_of_ee_points": 64}}})
+    try:
+        cfg = Config()
+        eng = InferenceEngine(allow_random_init=True, seed=3)
+        sc = mrcc_amd.synth.gen_scene(1, n_bg=6000, n_arm=800, n_ee=1500)
+        pts = sc["points"]
+        rgb = preprocess.normalize_colors(sc["rgb"])
+        # ---- segmentation
+        got = eng.predict_segmentation(pts, rgb)
+        sd = {k: v.cpu() for k, v in eng._segmentation_model.state_dict().items()}
+        ref = oracle.predict_segmentation(sd, pts, rgb, cfg.INFERENCE.SEGMENTATION.scale)
+        want = ref["label"].copy()
+        ee = np.where(want == 2)[0]
+        want[ee] = 1
+        if len(ee) > 1:
+            want[ee[eng.cluster_util.get_largest_cluster(pts[ref["label"] == 2])]] = 2
+        assert np.array_equal(got, want)
+        # ---- rotation head on the ground-truth end-effector crop
+        ee_idx = np.where(sc["segmentation"] == 2)[0]
+        ee_pts, ee_rgb = pts[ee_idx], rgb[ee_idx]
+        q = eng.predict_rotation(ee_pts, torch.from_numpy(ee_rgb))
+        p = ee_pts
+        if cfg.INFERENCE.ROTATION.center_at_origin:
+            p, _ = preprocess.center_at_origin(p)
+        c4 = np.concatenate([np.zeros((len(p), 1), np.float32), (torch.from_numpy(p) * cfg.INFERENCE.ROTATION.scale).numpy()], 1)
+        vox = oracle.voxelize(c4)
+        feats = oracle.voxel_reduce(ee_rgb, vox["order"], vox["seg_start"], 0)
+        sdr = {k: v.cpu() for k, v in eng._rotation_model.state_dict().items()}
+        fwd = oracle.robotnet_encode_forward if cfg.INFERENCE.ROTATION.encode_only else oracle.robotnet_forward
+        want_q = fwd(sdr, feats, oracle.Frame(vox["coords"]))[0][3:]
+        assert q.shape == want_q.shape and np.abs(q - want_q).max() < 1e-4
+        # ---- key-point pose (Kabsch on the device) and the ADD the harness would report for it
+        kp_classes = np.array([0, 1, 3, 4, 5])
+        pose = eng.predict_pose_from_kp(sc["key_points"][kp_classes], kp_classes)
+        Ro, to = oracle.get_rigid_transform_3D(mrcc_amd.synth.REFERENCE_KEY_POINTS[kp_classes], sc["key_points"][kp_classes])
+        qo = oracle.get_q_from_matrix(Ro)
+        assert np.abs(pose[:3] - to).max() < 1e-9 and min(np.abs(pose[3:] - qo).max(), np.abs(pose[3:] + qo).max()) < 1e-9
+        local = (ee_pts.astype(np.float64) - sc["pose"][:3]) @ mrcc_amd.synth.quat_to_matrix(sc["pose"][3:])
+        add_gpu = M.compute_ADD_np(local, sc["pose"], pose)
+        add_ora = oracle.compute_ADD_np(local, sc["pose"], np.concatenate([to, qo]))
+        assert abs(add_gpu - add_ora) < 1e-9 and add_gpu < 5e-3  # 1 mm key-point noise
+        assert eng.predict_pose_from_kp(sc["key_points"][:3], np.arange(3)) is None  # fewer than 4 key points (:384-386)
+    finally:
+        Config.reset()
