@@ -229,6 +229,12 @@ int sv_fps(const float* xyz, int B, int N, int S, const int64_t* start, int64_t*
  * scalar radius**2); the distance uses the reference's expanded form (-2ab + a^2 + b^2) in float32. */
 int sv_ball_query(const float* xyz, const float* new_xyz, int B, int N, int S, double radius, int nsample,
                   int64_t* out, sv_stream_t stream);
+/* PointNetFeaturePropagation's interpolation (model/pointnet2_utils.py:298-305): out[b][n][:] = sum over the three
+ * nearest xyz2 points of points2 rows weighted by 1 / (d + 1e-8), normalised; d in the reference's expanded float32
+ * form, nearest first, ties to the lower index.  xyz1 float32[B][N][3], xyz2 [B][S][3] (S >= 3), points2 [B][S][C],
+ * out [B][N][C]. */
+int sv_three_nn_interpolate(const float* xyz1, const float* xyz2, const float* points2, int B, int N, int S, int C,
+                            float* out, sv_stream_t stream);
 
 #ifdef __cplusplus
 }

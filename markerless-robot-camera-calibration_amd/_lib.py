@@ -61,6 +61,7 @@ SIGNATURES = {
     "sv_icp_point2point": (c_int, [_P, c_int64, _P, c_int64, _P, c_double, c_int, c_double, c_double, _P, c_size_t, _P, _P,
                                    _P]),
     "sv_fps": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
+    "sv_three_nn_interpolate": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "sv_ball_query": (c_int, [_P, _P, c_int, c_int, c_int, c_double, c_int, _P, _P]),
 }
 

@@ -222,11 +222,90 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict
   for (int j = count + lane; j < nsample; j += 64) dst[j] = first;
 }
 
+// ---- 3-nearest-neighbour inverse-distance interpolation (PointNetFeaturePropagation.forward,
+//      model/pointnet2_utils.py:298-305): a workgroup serves 64 query points.  Phase 1: one thread per query walks the S
+//      source points (staged through LDS, 256 at a time) with the reference's expanded float32 distance
+//      (-2 q.p + |q|^2) + |p|^2 and keeps the three smallest (ascending, first index wins a tie - the order of the
+//      reference's full sort); weights 1 / (d + 1e-8) normalised.  Phase 2: all 256 threads write out[q][c], channel fastest.
+__global__ __launch_bounds__(256) void three_nn_interpolate_kernel(const float* __restrict__ xyz1,
+                                                                    const float* __restrict__ xyz2,
+                                                                    const float* __restrict__ points2, int N, int S, int C,
+                                                                    float* __restrict__ out) {
+  __shared__ float src[256 * 3];
+  __shared__ int nn_idx[64 * 3];
+  __shared__ float nn_w[64 * 3];
+  const int b = blockIdx.y;
+  const int q0 = blockIdx.x * 64;
+  const float* x1 = xyz1 + (int64_t)b * N * 3;
+  const float* x2 = xyz2 + (int64_t)b * S * 3;
+  const int q = q0 + threadIdx.x;
+  const bool active = threadIdx.x < 64 && q < N;
+  float qx = 0.f, qy = 0.f, qz = 0.f, qq = 0.f;
+  if (active) {
+    qx = x1[q * 3 + 0];
+    qy = x1[q * 3 + 1];
+    qz = x1[q * 3 + 2];
+    qq = (qx * qx + qy * qy) + qz * qz;
+  }
+  float d0 = INFINITY, d1 = INFINITY, d2 = INFINITY;
+  int i0 = 0, i1 = 0, i2 = 0;
+  for (int s0 = 0; s0 < S; s0 += 256) {
+    const int cnt = min(256, S - s0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < cnt * 3; e += 256) src[e] = x2[(int64_t)s0 * 3 + e];
+    __syncthreads();
+    if (active) {
+      for (int j = 0; j < cnt; ++j) {
+        const float px = src[j * 3], py = src[j * 3 + 1], pz = src[j * 3 + 2];
+        const float dot = (qx * px + qy * py) + qz * pz;
+        const float pp = (px * px + py * py) + pz * pz;
+        const float d = (-2.0f * dot + qq) + pp;
+        const int i = s0 + j;
+        if (d < d2) {
+          if (d < d1) {
+            d2 = d1; i2 = i1;
+            if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = i; }
+            else { d1 = d; i1 = i; }
+          } else { d2 = d; i2 = i; }
+        }
+      }
+    }
+  }
+  if (threadIdx.x < 64) {
+    float w0 = 1.0f / (d0 + 1e-8f), w1 = 1.0f / (d1 + 1e-8f), w2 = 1.0f / (d2 + 1e-8f);
+    const float ws = (w0 + w1) + w2;
+    nn_idx[threadIdx.x * 3 + 0] = i0; nn_idx[threadIdx.x * 3 + 1] = i1; nn_idx[threadIdx.x * 3 + 2] = i2;
+    nn_w[threadIdx.x * 3 + 0] = w0 / ws; nn_w[threadIdx.x * 3 + 1] = w1 / ws; nn_w[threadIdx.x * 3 + 2] = w2 / ws;
+  }
+  __syncthreads();
+  const float* p2 = points2 + (int64_t)b * S * C;
+  float* o = out + ((int64_t)b * N + q0) * C;
+  const int nq = min(64, N - q0);
+  for (int e = threadIdx.x; e < nq * C; e += 256) {
+    const int ql = e / C, c = e - ql * C;
+    const float v = (p2[(int64_t)nn_idx[ql * 3] * C + c] * nn_w[ql * 3] + p2[(int64_t)nn_idx[ql * 3 + 1] * C + c] * nn_w[ql * 3 + 1]) +
+                    p2[(int64_t)nn_idx[ql * 3 + 2] * C + c] * nn_w[ql * 3 + 2];
+    o[e] = v;
+  }
+}
+
 }  // namespace sv
 
 using namespace sv;
 
 extern "C" {
+
+int sv_three_nn_interpolate(const float* xyz1, const float* xyz2, const float* points2, int B, int N, int S, int C,
+                            float* out, sv_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SV_CHECK_ARG(B >= 0 && N >= 1 && S >= 3 && C >= 1, "bad shape (S >= 3 source points)");
+  if (B == 0) return SV_OK;
+  SV_CHECK_ARG(xyz1 && xyz2 && points2 && out, "null pointer");
+  hipLaunchKernelGGL(three_nn_interpolate_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)B), dim3(256), 0, stream, xyz1,
+                     xyz2, points2, N, S, C, out);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
 
 int sv_fps(const float* xyz, int B, int N, int S, const int64_t* start, int64_t* out, sv_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;

@@ -139,6 +139,22 @@ class PointNetSetAbstraction(nn.Module):
         return new_xyz.permute(0, 2, 1), pooled
 
 
+def three_nn_interpolate(xyz1, xyz2, points2):
+    """[B,N,3], [B,S,3], [B,S,C] -> [B,N,C]: 3-NN inverse-distance interpolation on libsvhip (sv_three_nn_interpolate),
+    replacing the reference's full [B,N,S] distance matrix + sort (model/pointnet2_utils.py:298-305)."""
+    from ctypes import c_int
+
+    from .._lib import call, ptr, stream_ptr
+
+    B, N, _ = xyz1.shape
+    S, C = points2.shape[1], points2.shape[2]
+    x1, x2, p2 = (t.to(torch.float32).contiguous() for t in (xyz1, xyz2, points2))
+    out = torch.empty((B, N, C), dtype=torch.float32, device=x1.device)
+    call("sv_three_nn_interpolate", ptr(x1), ptr(x2), ptr(p2), c_int(B), c_int(N), c_int(S), c_int(C), ptr(out),
+         stream_ptr())
+    return out
+
+
 class PointNetFeaturePropagation(nn.Module):
     def __init__(self, in_channel, mlp):
         super().__init__()
@@ -159,6 +175,8 @@ class PointNetFeaturePropagation(nn.Module):
         S = xyz2.shape[1]
         if S == 1:
             interpolated = points2.repeat(1, N, 1)
+        elif not self.training and xyz1.is_cuda and S >= 3:
+            interpolated = three_nn_interpolate(xyz1, xyz2, points2)
         else:
             dists, idx = square_distance(xyz1, xyz2).topk(3, dim=-1, largest=False, sorted=True)
             recip = 1.0 / (dists + 1e-8)

@@ -199,3 +199,24 @@ def test_preprocess_device_path_vs_reference_golden(gpu, golden):
     assert np.array_equal(c1.cpu().numpy(), want_c) and np.array_equal(o1.cpu().numpy(), want_o)
     c2, _ = P.center_at_origin(t(wide)[:, 1:4])
     assert torch.equal(c1, c2)
+
+
+@pytest.mark.parametrize("B,N,S,C", [(2, 500, 64, 38), (1, 2048, 1024, 256), (3, 70, 3, 5), (1, 64, 300, 1)])
+def test_three_nn_interpolation_matches_reference_formulation(gpu, B, N, S, C):
+    """A8: PointNetFeaturePropagation's interpolation (model/pointnet2_utils.py:298-305: full distance matrix, sort,
+    first three, 1 / (d + 1e-8) weights) on sv_three_nn_interpolate.  Indices exact wherever the three nearest
+    distances are separated; values within 1e-5 (torch.matmul's rounding order inside square_distance is unspecified)."""
+    from mrcc_amd.model import pointnet2_utils as P2
+
+    g = torch.Generator().manual_seed(B * 1000 + N + S + C)
+    xyz1 = torch.rand(B, N, 3, generator=g) - 0.5
+    xyz2 = torch.rand(B, S, 3, generator=g) - 0.5
+    pts2 = torch.randn(B, S, C, generator=g)
+    got = P2.three_nn_interpolate(xyz1.to(gpu), xyz2.to(gpu), pts2.to(gpu)).cpu()
+    d, idx = P2.square_distance(xyz1.double(), xyz2.double()).sort(dim=-1)
+    d, idx = d[:, :, :3].float(), idx[:, :, :3]
+    w = 1.0 / (d + 1e-8)
+    w = w / w.sum(dim=2, keepdim=True)
+    want = torch.sum(P2.index_points(pts2, idx) * w.view(B, N, 3, 1), dim=2)
+    assert got.shape == want.shape == (B, N, C)
+    assert (got - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
