@@ -139,7 +139,7 @@ __device__ __forceinline__ void conv_tile_body(const ConvParams& p, const int bi
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
-  unsigned long long trace_t0 = 0;
+  unsigned long long trace_t0 = 0, trace_t_loop = 0, trace_t_epi = 0;
   int trace_steps = 0;
   if (p.trace) trace_t0 = wall_clock64();
   // 1-D grid, longest tiles first (list scheduling): plan tiles are visited in the plan's tile_order (sorted by active
@@ -347,6 +347,7 @@ __device__ __forceinline__ void conv_tile_body(const ConvParams& p, const int bi
     }
     __syncthreads();
     int buf = 0;
+    if (p.trace) trace_t_loop = wall_clock64();
 
     // one pipeline step; r_issue receives the gathers requested at its start, r_store holds the rows of step x
     auto step = [&](float4 (&r_issue)[A_F4], float4 (&r_store)[A_F4]) -> bool {
@@ -468,6 +469,7 @@ __device__ __forceinline__ void conv_tile_body(const ConvParams& p, const int bi
     }
   }
 
+  if (p.trace) trace_t_epi = wall_clock64();
   // ---- epilogue: BN(eval)/bias -> residual -> activation -> store.  C/D map: MFMA col = lane&15, row = (lane>>4)*4+reg
   float sc[NT], sh[NT];
 #pragma unroll
@@ -521,7 +523,10 @@ __device__ __forceinline__ void conv_tile_body(const ConvParams& p, const int bi
     t[1] = wall_clock64();
     t[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
            (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
-    t[3] = (unsigned)trace_steps;
+    // steps | prologue (start -> first step) and epilogue-start offsets in 100 MHz ticks / 16 (experiments)
+    const unsigned long long pro = trace_t_loop ? ((trace_t_loop - trace_t0) >> 4) & 0xffffull : 0ull;
+    const unsigned long long epi = ((t[1] - trace_t_epi) >> 4) & 0xffffull;
+    t[3] = (unsigned long long)(unsigned)trace_steps | (pro << 32) | (epi << 48);
   }
 }
 

@@ -20,6 +20,12 @@ hw = (t[:, 2] & np.uint64(0xffffffff)).astype(np.int64); xcc = (t[:, 2] >> np.ui
 cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7
 cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
 steps = (t[:, 3] & np.uint64(0xffffffff)).astype(np.int64)
+pro = ((t[:, 3] >> np.uint64(32)) & np.uint64(0xffff)).astype(np.float64) * 16 / 100.0   # us: start -> first pipeline step
+epi = ((t[:, 3] >> np.uint64(48)) & np.uint64(0xffff)).astype(np.float64) * 16 / 100.0   # us: epilogue start -> end
+if pro.max() > 0:
+    print(f"prologue (start -> first step) us: median {np.median(pro):.1f} mean {pro.mean():.1f} p90 {np.percentile(pro, 90):.1f}; "
+          f"epilogue us: median {np.median(epi):.1f} mean {epi.mean():.1f} p90 {np.percentile(epi, 90):.1f}; "
+          f"share of workgroup time: {(pro.sum() + epi.sum()) / ((t[:, 1].astype(np.int64) - t[:, 0].astype(np.int64)).sum() / 100.0) * 100:.1f} %")
 dur = t1 - t0
 T = t1.max()
 print(f"kernel span {T:.0f} us; workgroups {len(t)}; distinct CUs {len(np.unique(cuid))}; WG duration min/median/max {dur.min():.0f}/{np.median(dur):.0f}/{dur.max():.0f} us")
