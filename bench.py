@@ -149,7 +149,7 @@ def run_frames(model, pipe, frames, steps, hist=None):
     return voxels
 
 
-def oracle_pass(model, budget_s=25.0):
+def oracle_pass(model, budget_s=25.0, world=1):
     """Run the oracle (C restatement, OpenMP over output rows) on the host cores, timed: a quarter-size frame first,
     the full 200k-point seed-0 frame only if the estimate says it fits the budget.  Returns (cpu_baseline record,
     checked frame = dict(pts, rgb, lab, ref) of the LARGEST frame the oracle labelled)."""
@@ -157,10 +157,12 @@ def oracle_pass(model, budget_s=25.0):
     import sv_oracle as O
 
     cores = len(os.sched_getaffinity(0))
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    # explicit thread count: torch.distributed.run exports OMP_NUM_THREADS=1 to every rank, and the other ranks of this
+    # host are parked in the final barrier while rank 0 checks the labels
+    O.NUM_THREADS = max(1, min(cores, 128) // (1 if world == 1 else 2))
     sd = {k: v.cpu() for k, v in model.state_dict().items()}
     pts, rgb, lab = mrcc_amd.synth.gen_room(POINTS // 4, ROOM / 2, 0)
-    _log(f"cpu baseline: oracle on a quarter-size frame, {cores} host threads")
+    _log(f"cpu baseline: oracle on a quarter-size frame, {O.NUM_THREADS} host threads")
     t0 = time.perf_counter()
     r = O.predict_segmentation(sd, pts, rgb, SCALE)
     t_small = time.perf_counter() - t0
@@ -170,7 +172,7 @@ def oracle_pass(model, budget_s=25.0):
     note = ("scalar order-preserving fmaf chain per output row (the bit-exact oracle, AVX2 across output channels, "
             "OpenMP over rows) - NOT a BLAS gather-GEMM; see cpu_baseline_gather_gemm for that")
     est_full = t_small * 4.0
-    mm = gather_gemm_baseline(sd, r["label"])
+    mm = gather_gemm_baseline(sd, r["label"]) if world == 1 else None
     if est_full <= budget_s:
         pts, rgb, lab = mrcc_amd.synth.gen_room(POINTS, ROOM, 0)
         _log("cpu baseline: oracle on the full 200k-point frame")
@@ -178,11 +180,11 @@ def oracle_pass(model, budget_s=25.0):
         r = O.predict_segmentation(sd, pts, rgb, SCALE)
         t_full = time.perf_counter() - t0
         checked = dict(pts=pts, rgb=rgb, lab=lab, ref=r, what=f"full frame ({POINTS} pts, seed 0)")
-        base = {"value": 1.0 / t_full, "unit": "frames/s", "cores": O.lib().or_num_threads(), "kind": "port",
+        base = {"value": 1.0 / t_full, "unit": "frames/s", "cores": O.NUM_THREADS, "kind": "port",
                 "sample": f"1 full frame: {POINTS} pts, {len(r['vox']['keys'])} voxels, {t_full:.2f} s "
                           f"(C oracle, OpenMP, fp32 fmaf chain; quarter frame took {t_small:.2f} s)", "note": note}
     else:
-        base = {"value": 1.0 / est_full, "unit": "frames/s", "cores": O.lib().or_num_threads(), "kind": "port",
+        base = {"value": 1.0 / est_full, "unit": "frames/s", "cores": O.NUM_THREADS, "kind": "port",
                 "sample": f"quarter-size frame ({POINTS // 4} pts, L={ROOM / 2} m, {v_small} voxels) took "
                           f"{t_small:.2f} s; value = 1 / (4 x that): work is linear in voxels", "note": note}
     return base, mm, checked
@@ -600,7 +602,7 @@ def main():
         if not args.no_cpu_baseline:
             # the oracle pass gives both the timed CPU baseline (reported at N = 1, as the contract says) and the
             # reference labels of the accuracy half of the metric (every N; the other ranks wait at the final barrier)
-            base, base_mm, checked = oracle_pass(model)
+            base, base_mm, checked = oracle_pass(model, world=world)
             _log("accuracy: GPU path vs oracle labels on " + checked["what"])
             line["accuracy"] = accuracy_block(model, device, checked)
             if world == 1:

@@ -22,6 +22,8 @@ import os
 
 import numpy as np
 
+NUM_THREADS = None  # threads of or_conv_fwd; None = OpenMP's default (OMP_NUM_THREADS, which torchrun sets to 1 per rank)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libsvoracle.so")
 _lib = None
@@ -229,7 +231,7 @@ def conv(feats, W, nbr, V_out, scale=None, shift=None, residual=None, act=ACT_NO
     shift = None if shift is None else _f32(shift).reshape(-1)
     residual = None if residual is None else _f32(residual)
     if nthreads is None:
-        nthreads = lib().or_num_threads()
+        nthreads = NUM_THREADS or lib().or_num_threads()
     lib().or_conv_fwd(_p(feats), ctypes.c_int64(feats.shape[1]), ctypes.c_int(Cin), _p(W), ctypes.c_int(K),
                       ctypes.c_int(Cout), _p(nbr), ctypes.c_int64(V_out), ctypes.c_int64(V_out), _p(scale), _p(shift),
                       _p(residual), ctypes.c_int64(Cout), ctypes.c_int(act), ctypes.c_float(slope), _p(out),
