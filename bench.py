@@ -46,7 +46,8 @@ def _spawn_ranks_if_needed():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(known.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    sys.stdout.write(res.stdout)
+    for ln in res.stdout.splitlines():  # stdout carries the JSON line only; anything else a rank printed goes to stderr
+        (sys.stdout if ln.startswith("{") else sys.stderr).write(ln + "\n")
     sys.stdout.flush()
     if res.returncode == 0 and not any(l.startswith("{") for l in res.stdout.splitlines()):
         sys.stderr.write("bench.py launcher: the ranks exited 0 without printing the JSON line\n")
