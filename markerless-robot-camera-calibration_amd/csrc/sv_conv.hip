@@ -627,6 +627,177 @@ __global__ __launch_bounds__(256) void linear_narrow_kernel(ConvParams p) {
   }
 }
 
+// ---- thin gather-bound layers (Cin = 32 -> Cout = 32: block1's four convs, conv1p1s2, conv2p2s2;
+//      model/backbone/minkunet.py:59-71).  14 flop per gathered byte: the layer is its gather, and a tile's life in the
+//      LDS-staged kernel above is a chain of dependent round trips (neighbour table -> barrier -> gather -> LDS -> barrier,
+//      then one gather per step).  Here ONE WAVE owns a 16-row sub-tile and never synchronises with anybody:
+//        * the sub-tile's active offsets are compacted into a list (ballot over the plan's submask words);
+//        * per active offset every lane gathers the CIN channels of ITS row straight into registers - lane (row li,
+//          group lq) loads float4s at channels 16 j + 4 lq .. + 3 - with D offsets in flight (register ring);
+//        * the matrix op wants lane group lq to hold channel 4 m + lq for op m: a 4 x 4 transpose between the four lane
+//          groups and four registers, done with two v_permlane32_swap + two v_permlane16_swap per float4 (gfx950), so
+//          the accumulation chain keeps its (offset ascending, channel ascending) order and every bit of the result;
+//        * weights (wave-uniform per offset, 4 KB) come from L1/L2 one offset ahead.
+//      No LDS traffic for the features, no barrier, D gathers in flight per wave from its first microsecond on.
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __attribute__((aligned(16))) float thin_zero_row[128];  // zero-initialised: the row an absent neighbour reads
+__device__ __forceinline__ void transpose4x4_lanegroups(float& r0, float& r1, float& r2, float& r3) {
+  // in: lane group g (16 lanes) holds X[g][i] in r_i; out: lane group g holds X[i][g] in r_i
+  u32x2_t a = __builtin_amdgcn_permlane32_swap(__float_as_uint(r0), __float_as_uint(r2), false, false);
+  u32x2_t b = __builtin_amdgcn_permlane32_swap(__float_as_uint(r1), __float_as_uint(r3), false, false);
+  u32x2_t c = __builtin_amdgcn_permlane16_swap(a.x, b.x, false, false);
+  u32x2_t d = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
+  r0 = __uint_as_float(c.x);
+  r1 = __uint_as_float(c.y);
+  r2 = __uint_as_float(d.x);
+  r3 = __uint_as_float(d.y);
+}
+
+template <int CIN, int COUT, int MR, int D>
+__global__ __launch_bounds__(256) void conv_thin_kernel(ConvParams p) {
+  constexpr int NT = COUT / 16;  // MFMA column tiles per wave; interleaved: column li of tile n = channel NT * li + n
+  constexpr int KS = CIN / 4;    // k-steps per offset
+  constexpr int G4 = CIN / 16;   // float4 gathers per lane, row and offset
+  // MR: 16-row sub-tiles per wave (they share every weight register: half the weight traffic per row at MR = 2);
+  // D: offsets in flight per wave (gather ring)
+  static_assert(CIN % 16 == 0 && COUT % 16 == 0 && NT >= 1 && NT <= 4 && (MR == 1 || MR == 2), "shape");
+  typedef float bvec_t __attribute__((ext_vector_type(NT)));
+  typedef float bvec_load_t __attribute__((ext_vector_type(NT), aligned(4)));
+  __shared__ int idx_s[4][32 * 16 * MR];
+  __shared__ int klist_s[4][32];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, lq = lane >> 4;
+  const int K = p.K;
+  constexpr int ROWS = 16 * MR;
+  // (giving every XCD a contiguous eighth of the plan, for L2 locality of the gathers, measured no different: 24 vs 25 us
+  //  at level 1, 53 vs 49 us at level 0)
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + wid) * ROWS;  // Vpad is a multiple of 128: every wave has its rows
+  const int64_t t128 = row0 / PLAN_TILE;
+  const int sub = (int)((row0 % PLAN_TILE) / 16);
+  // ---- active offsets of this wave's sub-tile(s), compacted; neighbour rows of its rows for every offset
+  const bool active = lane < K && ((p.submask[t128 * K + lane] >> sub) & ((1u << MR) - 1u));
+  const unsigned long long amask = __ballot(active);
+  const int nact = __popcll(amask);
+  if (active) klist_s[wid][__popcll(amask & ((1ull << lane) - 1ull))] = lane;
+  for (int e = lane; e < K * ROWS; e += 64) idx_s[wid][e] = p.nbr_s[(int64_t)(e / ROWS) * p.Vpad + row0 + (e % ROWS)];
+  __builtin_amdgcn_wave_barrier();  // same-wave LDS traffic is ordered; keep the compiler from moving reads above
+
+  f32x4 acc[MR][NT];
+#pragma unroll
+  for (int s = 0; s < MR; ++s)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[s][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 g[D][MR][G4];
+  bvec_t b[2][KS];
+  // Every load below is unconditional (slots past the end of the list re-read the last offset's weights and the zero
+  // row, their matrix ops then add fma(0, w, acc) = acc): the loop body is straight-line code, so hipcc can count its
+  // s_waitcnt vmcnt instead of draining the ring at every control-flow merge.
+  const int last = nact > 0 ? nact - 1 : 0;
+  auto offset_of = [&](int j) { return __builtin_amdgcn_readfirstlane(klist_s[wid][min(j, last)]); };
+  auto issue = [&](int j, float4 (&dst)[MR][G4]) {
+    const int k = offset_of(j);
+#pragma unroll
+    for (int s = 0; s < MR; ++s) {
+      const int n = idx_s[wid][k * ROWS + s * 16 + li];
+      const bool ok = n >= 0 && j < nact;
+      // an absent neighbour reads a row of zeros: the load stays unconditional and needs no select behind it (with
+      // `ok ? value : 0` hipcc sinks the load under the condition and waits for it at the merge)
+      const float* src = (ok ? p.in + (int64_t)n * p.in_ld : thin_zero_row) + 4 * lq;
+#pragma unroll
+      for (int jj = 0; jj < G4; ++jj) dst[s][jj] = *(const float4*)(src + 16 * jj);
+    }
+  };
+  auto load_w = [&](int j, bvec_t (&dst)[KS]) {
+    const float* wk = p.W + (int64_t)offset_of(j) * CIN * COUT + lq * COUT + NT * li;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) dst[ks] = *(const bvec_load_t*)(wk + 4 * ks * COUT);
+  };
+  auto compute = [&](float4 (&a)[MR][G4], bvec_t (&w)[KS]) {
+#pragma unroll
+    for (int jj = 0; jj < G4; ++jj) {
+      float am[MR][4];
+#pragma unroll
+      for (int s = 0; s < MR; ++s) {
+        am[s][0] = a[s][jj].x; am[s][1] = a[s][jj].y; am[s][2] = a[s][jj].z; am[s][3] = a[s][jj].w;
+        transpose4x4_lanegroups(am[s][0], am[s][1], am[s][2], am[s][3]);  // [m]: channel 16 jj + 4 m + lq of row li
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int s = 0; s < MR; ++s)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            acc[s][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[s][m], w[4 * jj + m][n], acc[s][n], 0, 0, 0);
+    }
+  };
+  if (nact > 0) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue(d, g[d]);
+    load_w(0, b[0]);
+    constexpr int U = (D % 2 == 0) ? D : 2 * D;  // unroll so that ring slot and weight buffer indices are static
+    for (int j0 = 0; j0 < nact; j0 += U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int j = j0 + u;
+        load_w(j + 1, b[(u + 1) & 1]);
+        compute(g[u % D], b[u & 1]);
+        issue(j + D, g[u % D]);
+      }
+    }
+  }
+  // ---- epilogue (as conv_tile_body): C/D map: MFMA col = lane & 15, row = (lane >> 4) * 4 + reg
+  const int col0 = NT * li;
+  float sc[NT], sh[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    sc[n] = p.scale ? p.scale[col0 + n] : 1.0f;
+    sh[n] = p.shift ? p.shift[col0 + n] : 0.0f;
+  }
+#pragma unroll
+  for (int s = 0; s < MR; ++s) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int64_t o = p.perm[row0 + s * 16 + lq * 4 + reg];
+      if (o < 0) continue;
+      float y[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        float v = acc[s][n][reg];
+        if (p.scale)
+          v = __builtin_fmaf(v, sc[n], sh[n]);
+        else if (p.shift)
+          v = v + sh[n];
+        y[n] = v;
+      }
+      if (p.residual) {
+        const float* res = p.residual + o * p.res_ld + col0;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) y[n] = y[n] + res[n];
+      }
+      float* dst = p.out + o * p.out_ld + col0;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        float v = y[n];
+        if (p.act == SV_ACT_RELU)
+          v = v < 0.f ? 0.f : v;  // NaN stays NaN, as torch.relu
+        else if (p.act == SV_ACT_LEAKY_RELU)
+          v = v > 0.f ? v : v * p.slope;
+        dst[n] = v;
+      }
+    }
+  }
+}
+
+static int launch_conv_thin(const ConvParams& p, hipStream_t stream) {
+  // one 16-row sub-tile per wave, four offsets in flight: 24 us for block1's 32->32 at level 1 (26.5k voxels) against 35 us
+  // on the LDS-staged fused-offset tile, 49 against 84 us at 88k voxels (2.65 TB/s on algorithmic gather-bytes).  Two
+  // sub-tiles per wave (shared weight registers) 27-28 / 48 us, three or six offsets in flight 26 / 51-54 us.
+  hipLaunchKernelGGL((conv_thin_kernel<32, 32, 1, 4>), dim3((unsigned)(p.Vpad / 64)), dim3(256), 0, stream, p);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
 // ---- first layer of the networks (conv0: Cin = 3 colour channels -> 32, 3x3x3, every voxel of the frame;
 //      model/backbone/minkunet.py:55-57).  5.8 flop per byte of gather traffic: the layer is its gather.  One THREAD
 //      per output voxel (in the plan's mask-sorted order, so a wavefront's rows share most neighbour offsets and an
@@ -962,6 +1133,8 @@ extern "C" int sv_conv_fwd(const float* in, int64_t in_ld, int Cin, const float*
   p.main_tiles128 = 0;
   static const bool no_first = getenv("SV_CONV_NO_FIRST") != nullptr;  // experiments only
   if (has_plan && K > 1 && K <= 27 && Cin == 3 && Cout == 32 && !no_first) return launch_conv_first_layer(p, stream);
+  static const bool no_thin = getenv("SV_CONV_NO_THIN") != nullptr;  // experiments only
+  if (has_plan && K > 1 && K <= 32 && Cin == 32 && Cout == 32 && p.vec_a && !no_thin) return launch_conv_thin(p, stream);
   static const bool no_narrow = getenv("SV_CONV_NO_NARROW") != nullptr;  // experiments only
   if (!has_plan && K == 1 && Cout <= 4 && p.vec_a && Cin >= 64 && !no_narrow) return launch_linear_narrow(p, stream);
   return select_and_launch(p, stream);

@@ -39,6 +39,8 @@ def conv_kernel_config(Cout, Vpad, Cin=None, K=1):
         return f"linear_narrow_kernel<{Cout}>"  # dense rows only; every K = 1 layer of the path is dense
     if K > 1 and Cin == 3 and Cout == 32:
         return "conv_first_layer_kernel<3, 32>"
+    if K > 1 and Cin == 32 and Cout == 32:
+        return "conv_thin_kernel<32, 32>"  # wave-per-sub-tile direct-gather kernel of the thin 32-channel layers
     fused = None
     if K > 1 and Cin is not None:
         if Cin == 3 and 16 < Cout <= 32:

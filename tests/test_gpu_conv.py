@@ -182,3 +182,42 @@ def test_relu_epilogue_propagates_nan_like_torch(gpu, oracle):
     y = svnn.affine_act(t(x), act=1).cpu().numpy()
     assert np.array_equal(np.isnan(y), np.isnan(x)) and np.array_equal(y[~np.isnan(x)], np.maximum(x, 0)[~np.isnan(x)])
     assert np.array_equal(np.isnan(torch.relu(torch.from_numpy(x)).numpy()), np.isnan(y))
+
+
+def test_thin_wave_per_subtile_kernel_strided_and_batched(gpu, oracle):
+    """conv_thin_kernel<32, 32> (one wave per 16-row sub-tile, direct register gathers, lane-group transposes): a column
+    slice of a wider buffer as input AND as output, a two-frame batch, every epilogue option, and the 8-offset maps."""
+    from mrcc_amd import nn as svnn
+    from mrcc_amd import profiling
+
+    ME, field, st, coords4 = _setup(gpu, n=9000, L=0.7, batch=2)
+    cm = st.coordinate_manager
+    frame = oracle.Frame(oracle.voxelize(coords4)["coords"])
+    V = st.F.shape[0]
+    plan = cm.plan_k3(1)
+    assert profiling.conv_kernel_config(32, plan.Vpad, 32, 27) == "conv_thin_kernel<32, 32>"
+    rng = np.random.default_rng(11)
+    wide_in = rng.normal(size=(V, 80)).astype(np.float32)
+    W = (rng.normal(size=(27, 32, 32)) * 0.1).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, size=32).astype(np.float32)
+    shift = rng.normal(size=32).astype(np.float32)
+    res = rng.normal(size=(V, 32)).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(gpu)
+    x = t(wide_in)[:, 16:48]  # row stride 80 floats, 16-byte aligned start
+    out_buf = torch.full((V, 96), 7.0, device=gpu)
+    svnn.conv_forward(x, t(W), plan, V, t(scale), t(shift), t(res), 2, 0.05, out=out_buf[:, 32:64])
+    want = oracle.conv(np.ascontiguousarray(wide_in[:, 16:48]), W, frame.k3(1), V, scale, shift, res, oracle.ACT_LEAKY, 0.05)
+    assert np.array_equal(out_buf[:, 32:64].cpu().numpy(), want)
+    assert (out_buf[:, :32] == 7.0).all() and (out_buf[:, 64:] == 7.0).all()  # neighbours of the slice untouched
+    # bias-only epilogue (no scale), no residual, no activation
+    got = svnn.conv_forward(x, t(W), plan, V, None, t(shift)).cpu().numpy()
+    assert np.array_equal(got, oracle.conv(np.ascontiguousarray(wide_in[:, 16:48]), W, frame.k3(1), V, None, shift))
+    # stride-2 down and transposed up maps (8 offsets)
+    Vc = len(frame.down(1))
+    W8 = (rng.normal(size=(8, 32, 32)) * 0.2).astype(np.float32)
+    xf = rng.normal(size=(V, 32)).astype(np.float32)
+    got = svnn.conv_forward(t(xf), t(W8), cm.plan_down(1), Vc, act=1).cpu().numpy()
+    assert np.array_equal(got, oracle.conv(xf, W8, frame.kdown(1), Vc, act=oracle.ACT_RELU))
+    xc = rng.normal(size=(Vc, 32)).astype(np.float32)
+    got = svnn.conv_forward(t(xc), t(W8), cm.plan_up(2), V).cpu().numpy()
+    assert np.array_equal(got, oracle.conv(xc, W8, frame.kup(2), V))
