@@ -137,11 +137,14 @@ int sv_plan_build(const int32_t* nbr, int64_t ld, const uint32_t* mask, int K, i
  *   y += residual[o][n]            (residual NULL = none)
  *   out[o][n] = act(y)
  * perm/nbr_s/submask NULL = dense rows (kernel_size 1 / Linear): nbr = identity.  tile_order may be NULL.
+ * V_in = rows of `in` (every index in nbr_s is below it; = V_out for dense rows): with it the wide-layer kernels
+ * address `in` through a bounds-checked buffer descriptor (32-bit offsets, absent neighbours read as zero rows);
+ * inputs of 2 GB and more take the guarded form with 64-bit addresses.
  * One entry point, several kernels behind it (all with the chain order above, so results do not depend on the
  * choice): fp32-MFMA tiles for the wide layers, their fused-offset form for 32/64-channel inputs, a thread-per-voxel
  * VALU kernel for the 3-channel first layer and a row-streaming VALU kernel for dense layers with <= 4 outputs.
  * ------------------------------------------------------------------------------------------- */
-int sv_conv_fwd(const float* in, int64_t in_ld, int Cin, const float* W, int K, int Cout, const int32_t* perm,
+int sv_conv_fwd(const float* in, int64_t V_in, int64_t in_ld, int Cin, const float* W, int K, int Cout, const int32_t* perm,
                 const int32_t* nbr_s, const uint32_t* submask, const int32_t* tile_order, int64_t V_out, int64_t Vpad,
                 const float* scale,
                 const float* shift, const float* residual, int64_t res_ld, int act, float slope, float* out,

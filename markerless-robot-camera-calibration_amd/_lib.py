@@ -43,8 +43,8 @@ SIGNATURES = {
     "sv_plan_build": (c_int, [_P, c_int64, _P, c_int, c_int64, _P, c_size_t, _P, _P, _P, _P, c_int64, _P]),
     "sv_conv_fwd": (
         c_int,
-        [_P, c_int64, c_int, _P, c_int, c_int, _P, _P, _P, _P, c_int64, c_int64, _P, _P, _P, c_int64, c_int, c_float,
-         _P, c_int64, _P],
+        [_P, c_int64, c_int64, c_int, _P, c_int, c_int, _P, _P, _P, _P, c_int64, c_int64, _P, _P, _P, c_int64, c_int,
+         c_float, _P, c_int64, _P],
     ),
     "sv_affine_act": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, _P, c_int64, c_int, c_float, _P, c_int64, _P]),
     "sv_col_stats_workspace_bytes": (c_size_t, [c_int64]),

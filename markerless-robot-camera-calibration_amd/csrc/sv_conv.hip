@@ -48,6 +48,9 @@ struct ConvParams {
   float* out;
   int64_t out_ld;
   int vec_a;  // in_ld % 4 == 0 && Cin % 4 == 0 && base aligned -> float4 gathers
+  // FAST instances address `in` and `W` through buffer descriptors with 32-bit byte offsets (see conv_tile_body):
+  uint32_t in_bytes, w_bytes;  // extents of the two buffers
+  int buf_ok;                  // both below BUF_LIMIT (else the guarded generic form with 64-bit addresses runs)
   int ntiles;
   int ny;
   unsigned long long* trace;  // SV_CONV_TRACE experiments: per-workgroup {start, end, hw id, steps}; null otherwise
@@ -56,6 +59,32 @@ struct ConvParams {
 };
 
 constexpr int PLAN_TILE = SV_TILE_ROWS;
+// Buffer addressing of the FAST instances.  Measured with tools/mfma_probe.py on gfx950: a `global_load` with a 64-bit
+// VGPR address costs the SIMD's matrix pipe ~45 cycles of issue per instruction (one per 12 matrix ops: 0.98 -> 0.86 of
+// the peak issue rate), and every VALU instruction in the loop (address arithmetic, selects) its own execution time;
+// `buffer_load` with a 32-bit VGPR offset and an SGPR offset costs nothing measurable (0.97).  Out-of-range offsets
+// return 0 without a memory access, which is how absent neighbours read as zero rows: no select, no branch.
+constexpr uint32_t BUF_ABSENT = 0x80000000u;  // byte offset of an absent neighbour's row: beyond every extent
+constexpr uint32_t BUF_LIMIT = 0x7fff0000u;   // extents stay below BUF_ABSENT minus the largest column offset
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef int i32x3_t __attribute__((ext_vector_type(3)));
+typedef int i32x2_t __attribute__((ext_vector_type(2)));
+template <int N>
+__device__ __forceinline__ auto buffer_load_floats(__amdgpu_buffer_rsrc_t rsrc, uint32_t voffset, uint32_t soffset) {
+  typedef float vec_t __attribute__((ext_vector_type(N)));
+  if constexpr (N == 1) {
+    vec_t r;
+    r[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voffset, soffset, 0));
+    return r;
+  } else if constexpr (N == 2) {
+    return __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voffset, soffset, 0));
+  } else if constexpr (N == 3) {
+    return __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b96(rsrc, voffset, soffset, 0));
+  } else {
+    static_assert(N == 4, "1..4 floats per load");
+    return __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0));
+  }
+}
 #ifndef SV_CONV_TAIL_DEFAULT
 #define SV_CONV_TAIL_DEFAULT 0.15  // share of the plan tiles (the cheapest) that chip-filling launches run as half-height tiles
 #endif  // plans (perm / nbr_s / submask) are laid out in 128-row tiles
@@ -178,8 +207,11 @@ __device__ __forceinline__ void conv_tile_body(const ConvParams& p, const int bi
       n = p.nbr_s[(int64_t)k * p.Vpad + row0 + r];
     else
       n = (row0 + r < p.V_out) ? (int)(row0 + r) : -1;
-    idx_s[e] = n;
+    // FAST: the table holds the row's BYTE offset in `in` (absent: beyond the buffer's extent -> the load returns 0)
+    idx_s[e] = FAST ? (int)(n >= 0 ? (uint32_t)n * (uint32_t)(p.in_ld * 4) : BUF_ABSENT) : n;
   }
+  const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)p.w_bytes, 0x00020000);
 
   // ---- step iterator over (active offset, chunk).  The plan's submask words cover 128 rows = 8 sub-tiles; lane k of
   //      every wave keeps the tile's word for offset k in a register and a ballot gives the active-offset set, so
@@ -235,24 +267,46 @@ __device__ __forceinline__ void conv_tile_body(const ConvParams& p, const int bi
 #define SV_GATHER_DEPTH 1
 #endif
   constexpr int GDEPTH = SV_GATHER_DEPTH;
+  // timing-only ablations (results WRONG; tools/build_variant.sh <name> -DSV_ABL=<bits>): 1 = no weight reloads in the
+  // loop, 2 = no gathers / LDS stores in the loop, 4 = no per-step barrier, 8 = A operands from a register, not LDS
+#ifndef SV_ABL
+#define SV_ABL 0
+#endif
+  constexpr int ABL = SV_ABL;
   float4 ra0[A_F4], ra1[A_F4];  // ra1 is dead (optimised away) at GDEPTH 1
   const int a_cc = (tid % Cfg::F4_PER_ROW) * 4;
   const int a_r = tid / Cfg::F4_PER_ROW;
 
+  // FAST: this thread's column inside a chunk in bytes; in a partial last chunk, threads past Cin use minus the chunk's
+  // start instead (voffset + soffset = the row's first columns)
+  const uint32_t col_bytes = (uint32_t)a_cc * 4u;
+  const int cin_rem = Cin % KC;
+  const uint32_t col_last = (cin_rem == 0 || a_cc < cin_rem) ? col_bytes : 0u - (uint32_t)(Cin - cin_rem) * 4u;
   auto load_a = [&](float4 (&ra)[A_F4], int k, int c0, uint32_t sm) {
 #pragma unroll
     for (int j = 0; j < A_F4; ++j) {
       const int r = a_r + ROWS_PER_PASS * j;
       if (FAST) {
+        // one ds_read (the row's byte offset), one add (this thread's column) and a buffer_load whose SGPR offset is the
+        // step's channel chunk: rows past the tile (clamped), sub-tiles without a neighbour at this offset (all their
+        // rows are absent) and absent neighbours need no test - the descriptor's range check returns zeros for them
         const int rr = (A_F4 * ROWS_PER_PASS > TM_) ? min(r, TM_ - 1) : r;
-        // fused offsets: column a_cc of the step belongs to offset k + a_cc / CPO, channel a_cc % CPO
-        const int kk = CPO ? k + a_cc / (CPO ? CPO : 1) : k;
-        const int c = CPO ? a_cc % (CPO ? CPO : 1) : c0 + a_cc;
-        const int n = idx_s[min(kk, K - 1) * TM_ + rr];
-        const bool ok = (r < TM_) && ((sm >> (rr >> 4)) & 1u) && (n >= 0) && (CPO ? kk < K : c < Cin);
-        const float* src = p.in + (ok ? ((int64_t)n * p.in_ld + c) : 0);
-        float4 v = *(const float4*)src;
-        ra[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (CPO) {
+          // fused offsets: column a_cc of the step belongs to offset k + a_cc / CPO, channel a_cc % CPO
+          const int kk = k + a_cc / (CPO ? CPO : 1);
+          uint32_t off = (uint32_t)idx_s[min(kk, K - 1) * TM_ + rr];
+          if (kk >= K) off = BUF_ABSENT;
+          const f32x4 v = buffer_load_floats<4>(rsrc_in, off + (uint32_t)(a_cc % (CPO ? CPO : 1)) * 4u, 0u);
+          ra[j] = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          const uint32_t off = (uint32_t)idx_s[k * TM_ + rr];
+          // the last chunk of a layer whose Cin is not a multiple of KC: columns past Cin are never multiplied; their
+          // lanes re-read the row's first columns (col_last) so that no load reaches past a row
+          const uint32_t cb = (!FULL && c0 + KC > Cin) ? col_last : col_bytes;
+          const f32x4 v = buffer_load_floats<4>(rsrc_in, off + cb, (uint32_t)c0 * 4u);
+          ra[j] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        (void)sm;
       } else if (CPO) {
         float e[4] = {0.f, 0.f, 0.f, 0.f};
         if (r < TM_ && ((sm >> (r >> 4)) & 1u)) {
@@ -291,7 +345,9 @@ __device__ __forceinline__ void conv_tile_body(const ConvParams& p, const int bi
 #pragma unroll
     for (int j = 0; j < A_F4; ++j) {
       const int r = a_r + ROWS_PER_PASS * j;
-      if (r < TM_ && ((sm >> (r >> 4)) & 1u)) {
+      // FAST: rows of sub-tiles that are inactive at this offset arrive as zeros and are stored like the others (their
+      // matrix ops are skipped anyway) - no per-row mask arithmetic in the loop
+      if (r < TM_ && (FAST || ((sm >> (r >> 4)) & 1u))) {
         float2* dst = (float2*)(dstbuf + r * SA + a_cc);
         dst[0] = make_float2(ra[j].x, ra[j].y);
         dst[1] = make_float2(ra[j].z, ra[j].w);
@@ -309,14 +365,17 @@ __device__ __forceinline__ void conv_tile_body(const ConvParams& p, const int bi
   // FAST: wstep = first weight row of the step (wave-uniform -> scalar registers), b_off = this lane's constant offset;
   // per k-step only a scalar add remains.  K-steps past the channel tail re-read row 0 of the step (never multiplied).
   const int b_off = lq * Cout + col0;
+  const uint32_t b_off_bytes = (uint32_t)b_off * 4u;
   auto step_weights = [&](int k, int c0) -> const float* { return p.W + ((int64_t)k * Cin + c0) * Cout; };
   // valid A columns of the step starting at (k, c0): the rest of the chunk is zero padding
   auto cols_of = [&](int k, int c0) { return CPO ? min(GK, K - k) * CPO : min(KC, Cin - c0); };
   auto ksteps_of = [&](int k, int c0) { return (cols_of(k, c0) + 3) >> 2; };
   auto load_b = [&](const float* wstep, int k, int c0, int ksteps_valid, int ks, bvec_t& dst) {
     if (FAST) {
-      const float* src = wstep + (int64_t)(ks < ksteps_valid ? 4 * ks : 0) * Cout;
-      dst = *(const bvec_load_t*)(src + b_off);
+      // SGPR offset = the k-step's first weight row, VGPR offset = this lane's constant (row lq, column col0)
+      const uint32_t row = (uint32_t)(k * Cin + c0 + (ks < ksteps_valid ? 4 * ks : 0));
+      dst = buffer_load_floats<NT>(rsrc_w, b_off_bytes, row * (uint32_t)Cout * 4u);
+      (void)wstep;
     } else {
       // W row of A column i of the step: (k * Cin + c0 + i) - fused offsets are consecutive row blocks of W
       const int i = 4 * ks + lq;
@@ -354,7 +413,8 @@ __device__ __forceinline__ void conv_tile_body(const ConvParams& p, const int bi
       // ---- gathers go out first: they land during matrix work and are written to the other LDS buffer at the end of
       //      this step (GDEPTH 1) or of the next one (GDEPTH 2).  (Issued here rather than after the barrier so that
       //      a conservative wait on the loop back-edge never waits for a gather that was just issued.)
-      if (GDEPTH == 1) {
+      if (ABL & 2) {
+      } else if (GDEPTH == 1) {
         if (FAST || have_x) load_a(r_issue, have_x ? k_x : 0, have_x ? c_x : 0, have_x ? sm_x : 0u);
       } else {
         const bool have2 = have_x && have_n;
@@ -376,9 +436,9 @@ __device__ __forceinline__ void conv_tile_body(const ConvParams& p, const int bi
       // weight-row addressing, i.e. no per-k-step compare / select / branch in the hot loop.
       {
         auto reload_b = [&](int ks) {
+          if (ABL & 1) return;
           if (FULL) {
-            const float* src = wnext + (int64_t)(4 * ks) * Cout;
-            b[ks] = *(const bvec_load_t*)(src + b_off);
+            b[ks] = buffer_load_floats<NT>(rsrc_w, b_off_bytes, (uint32_t)(kb * Cin + cb + 4 * ks) * (uint32_t)Cout * 4u);
           } else if (FAST || have_x) {
             load_b(wnext, kb, cb, ksteps_next, ks, b[ks]);
           }
@@ -405,7 +465,7 @@ __device__ __forceinline__ void conv_tile_body(const ConvParams& p, const int bi
               float a_nx[MR];
               if (ks + 1 < KC / 4) {
 #pragma unroll
-                for (int s = 0; s < MR; ++s) a_nx[s] = a_base[s * 16 * SA + (ks + 1) * 4];
+                for (int s = 0; s < MR; ++s) a_nx[s] = (ABL & 8) ? a_cur[s] : a_base[s * 16 * SA + (ks + 1) * 4];
                 if (FULL) __builtin_amdgcn_sched_barrier(0);  // operand reads go out first
               }
               mfma_row(ks, a_cur);
@@ -444,7 +504,7 @@ __device__ __forceinline__ void conv_tile_body(const ConvParams& p, const int bi
       ++trace_steps;
       if (!have_x) return false;
       // ---- hand over to step x
-      store_a(r_store, As + (buf ^ 1) * (TM_ * SA), sm_x);
+      if (!(ABL & 2)) store_a(r_store, As + (buf ^ 1) * (TM_ * SA), sm_x);
       k_c = k_x;
       c_c = c_x;
       sm_c = sm_x;
@@ -454,7 +514,7 @@ __device__ __forceinline__ void conv_tile_body(const ConvParams& p, const int bi
       sm_x = sm_n;
       have_x = have_n;
       if (GDEPTH == 2 && have_n) advance();
-      __syncthreads();
+      if (!(ABL & 4)) __syncthreads();
       buf ^= 1;
       return true;
     };
@@ -908,7 +968,7 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
   q.ntiles = (int)(p.Vpad / TM_);
   q.ny = (p.Cout + Cfg::TN - 1) / Cfg::TN;
   dim3 grid((unsigned)(q.ntiles * q.ny));
-  const bool fast = p.vec_a && (p.Cout % Cfg::TN == 0);
+  const bool fast = p.vec_a && p.buf_ok && (p.Cout % Cfg::TN == 0);
   // SV_CONV_TRACE=<file> (experiments only): trace the launch per workgroup, synchronise, append to <file>
   // (tools/wg_trace.py reads it: residency over time, per-CU tail, time per step)
   static const char* trace_path = getenv("SV_CONV_TRACE");
@@ -961,7 +1021,7 @@ template <int TM_, int TAIL_TM, int WAVES_N, int NT>
 static int launch_conv_dual(const ConvParams& p, hipStream_t stream, double tail_fraction) {
   using Main = ConvCfg<TM_, WAVES_N, NT, 0>;
   using Tail = ConvCfg<TAIL_TM, WAVES_N, NT, 0>;
-  const bool fast = p.vec_a && (p.Cout % Main::TN == 0);
+  const bool fast = p.vec_a && p.buf_ok && (p.Cout % Main::TN == 0);
   const int n128 = (int)(p.Vpad / PLAN_TILE);
   const int tail128 = (int)(n128 * tail_fraction);
   if (!fast || !p.tile_order || tail128 < 1 || tail128 >= n128) return SV_ERR_INVALID;
@@ -1105,7 +1165,7 @@ static int select_and_launch(const ConvParams& p, hipStream_t stream) {
 
 using namespace sv;
 
-extern "C" int sv_conv_fwd(const float* in, int64_t in_ld, int Cin, const float* W, int K, int Cout,
+extern "C" int sv_conv_fwd(const float* in, int64_t V_in, int64_t in_ld, int Cin, const float* W, int K, int Cout,
                            const int32_t* perm, const int32_t* nbr_s, const uint32_t* submask,
                            const int32_t* tile_order, int64_t V_out, int64_t Vpad, const float* scale, const float* shift, const float* residual, int64_t res_ld,
                            int act, float slope, float* out, int64_t out_ld, sv_stream_t stream_) {
@@ -1116,6 +1176,7 @@ extern "C" int sv_conv_fwd(const float* in, int64_t in_ld, int Cin, const float*
   SV_CHECK_ARG(act >= SV_ACT_NONE && act <= SV_ACT_LEAKY_RELU, "bad activation");
   if (V_out == 0) return SV_OK;
   SV_CHECK_ARG(in && W && out, "null pointer");
+  SV_CHECK_ARG(V_in >= 1, "V_in = rows of `in` (every index of the plan is below it)");
   const bool has_plan = perm || nbr_s || submask;
   SV_CHECK_ARG(!has_plan || (perm && nbr_s && submask), "perm, nbr_s and submask must be given together");
   SV_CHECK_ARG(has_plan || K == 1, "K > 1 needs a plan");
@@ -1126,6 +1187,12 @@ extern "C" int sv_conv_fwd(const float* in, int64_t in_ld, int Cin, const float*
   p.scale = scale; p.shift = shift; p.residual = residual; p.res_ld = res_ld;
   p.act = act; p.slope = slope; p.out = out; p.out_ld = out_ld;
   p.vec_a = (in_ld % 4 == 0) && (Cin % 4 == 0) && (((uintptr_t)in & 15) == 0);
+  // extents for the buffer descriptors of the FAST instances: `in` through the last channel of its last row
+  const uint64_t in_bytes = ((uint64_t)(V_in - 1) * (uint64_t)in_ld + (uint64_t)Cin) * 4u;
+  const uint64_t w_bytes = (uint64_t)K * (uint64_t)Cin * (uint64_t)Cout * 4u;
+  p.buf_ok = in_bytes < BUF_LIMIT && w_bytes < BUF_LIMIT;
+  p.in_bytes = p.buf_ok ? (uint32_t)in_bytes : 0u;
+  p.w_bytes = p.buf_ok ? (uint32_t)w_bytes : 0u;
   p.ntiles = 0;
   p.ny = 0;
   p.trace = nullptr;

@@ -50,7 +50,8 @@ def conv_forward(feats, weight3, plan, V_out, scale=None, shift=None, residual=N
         kname = profiling.conv_kernel_config(Cout, Vpad, Cin, K)
         if timer.want(kname):
             t0 = timer.start()
-    call("sv_conv_fwd", ptr(feats), c_int64(feats.stride(0)), c_int(Cin), ptr(weight3), c_int(K), c_int(Cout),
+    call("sv_conv_fwd", ptr(feats), c_int64(feats.shape[0]), c_int64(feats.stride(0)), c_int(Cin), ptr(weight3), c_int(K),
+         c_int(Cout),
          ptr(perm), ptr(nbr_s), ptr(submask), ptr(tile_order), c_int64(V_out), c_int64(Vpad), ptr(scale), ptr(shift),
          ptr(residual),
          c_int64(residual.stride(0) if residual is not None else 0), c_int(act), c_float(slope), ptr(out),

@@ -30,10 +30,10 @@ def test_argument_validation_without_gpu():
     import mrcc_amd
 
     lib = mrcc_amd._lib.load()
-    rc = lib.sv_conv_fwd(None, 4, 4, None, 27, 4, None, None, None, None, 10, 128, None, None, None, 0, 0,
+    rc = lib.sv_conv_fwd(None, 10, 4, 4, None, 27, 4, None, None, None, None, 10, 128, None, None, None, 0, 0,
                          ctypes.c_float(0.0), None, 4, None)
     assert rc == -1 and b"null pointer" in lib.sv_last_error()
-    rc = lib.sv_conv_fwd(None, 4, 4, None, 1, 4, None, None, None, None, 10, 100, None, None, None, 0, 0,
+    rc = lib.sv_conv_fwd(None, 10, 4, 4, None, 1, 4, None, None, None, None, 10, 100, None, None, None, 0, 0,
                          ctypes.c_float(0.0), None, 4, None)
     assert rc == -1 and b"multiple of 128" in lib.sv_last_error()
     rc = lib.sv_hash_build(None, 10, None, None, 24, None)

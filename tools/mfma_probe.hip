@@ -58,7 +58,165 @@ __global__ __launch_bounds__(256) void mfma_lds_kernel(float* out, int iters) {
     if (s == 123.456f) out[0] = s;
 }
 
+// What does an instruction of another class cost the matrix pipe?  The LDS-fed loop above plus, per k-step of 12 matrix
+// ops (MODE bits): 1 = one global_load_dwordx3 from a cache-resident 48 KB block (the weight reload), 2 = two
+// global_load_dwordx4 per 8 k-steps from random rows of a big buffer (the gathers), 4 = two 64-bit VALU adds per
+// k-step, 16 = four ds_write_b64 + barrier per 8 k-steps.  Waits as in conv_tile_body: a k-step waits for the weight row
+// requested 8 k-steps earlier (s_waitcnt vmcnt(7)), the end of a step for its two gathers.  Loaded values are never read.
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+template <int MODE>
+__global__ __launch_bounds__(256) void mfma_mix_kernel(float* out, const float* wbuf, const float* big, long long big_rows,
+                                                       int iters) {
+    __shared__ float tile[2 * 64 * 34];
+    for (int i = threadIdx.x; i < 2 * 64 * 34; i += 256) tile[i] = 1e-9f * i;
+    __syncthreads();
+    f32x4 acc[4][3];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int lane = threadIdx.x & 63;
+    float b[3] = {1.0f, 1.0f + 1e-9f * blockIdx.x, 0.5f};
+    const float* pb = wbuf + (lane >> 4) * 384 + (lane & 15) * 3 + (threadIdx.x >> 6) * 48;
+    unsigned long long rnd = 0x9E3779B97F4A7C15ull * (blockIdx.x * 32 + (threadIdx.x >> 3) + 1);  // 8 lanes share a row
+    unsigned long long vaddr = (unsigned long long)pb;
+    int sacc = blockIdx.x;
+    // destinations stay allocated until the s_waitcnt at the end of the step (a load must never land in a register the
+    // compiler has meanwhile given to an address)
+    f32x4 gv[2];
+    f32x3 wv[8];
+    for (int i = 0; i < iters; ++i) {
+        if (MODE & 2) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                rnd = rnd * 6364136223846793005ull + 1442695040888963407ull;
+                const float* src = big + ((rnd >> 20) % (unsigned long long)big_rows) * 384 + (threadIdx.x & 7) * 4;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gv[g]) : "v"(src) : "memory");
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (MODE & 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                float a = tile[(m * 16 + (lane & 15)) * 34 + k * 4 + (lane >> 4)];
+#pragma unroll
+                for (int n = 0; n < 3; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[n], acc[m][n], 0, 0, 0);
+            }
+            if (MODE & 1) {
+                asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(wv[k]) : "v"(pb + k * 4 * 384) : "memory");
+            }
+            if (MODE & 4) {
+                asm volatile("v_lshl_add_u64 %0, %0, 0, %1\n\tv_lshl_add_u64 %0, %0, 0, %1" : "+v"(vaddr) : "v"(rnd));
+            }
+        }
+        // the gathered rows are needed now (in-order return: they are older than this step's 8 weight reloads)
+        if ((MODE & 3) == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (MODE & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (MODE & 2) asm volatile("" ::"v"(gv[0]), "v"(gv[1]));
+        if (MODE & 16) {
+            float2* dst = (float2*)(tile + ((i & 1) ^ 1) * 64 * 34 + (threadIdx.x >> 3) * 34 + (threadIdx.x & 7) * 4);
+            dst[0] = make_float2(b[0], b[1]);
+            dst[1] = make_float2(b[1], b[2]);
+            dst[32 * 17] = make_float2(b[0], b[1]);
+            dst[32 * 17 + 1] = make_float2(b[1], b[2]);
+            __syncthreads();
+        }
+        if (MODE & 1)
+            asm volatile("" ::"v"(wv[0]), "v"(wv[1]), "v"(wv[2]), "v"(wv[3]), "v"(wv[4]), "v"(wv[5]), "v"(wv[6]), "v"(wv[7]));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float s = (float)(vaddr & 1) + (float)(sacc & 1);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) s += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
+    if (s == 123.456f) out[0] = s;
+}
+
+// Which part of the weight reload costs matrix-pipe time?  One load per k-step of 12 matrix ops in different forms
+// (LD): 0 = global_load_dwordx3 v, v[addr 64-bit], off + s_waitcnt vmcnt(7) per k-step; 1 = same load, no wait in the
+// loop (drain per step); 2 = the waits without the loads; 3 = global_load_dwordx3 v, v_offset, s[base]; 4 = dword
+// instead of dwordx3; 5 = buffer_load_dwordx3 (resource descriptor + 32-bit offset); 6 = ds_read_b96 from LDS.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+template <int LD>
+__global__ __launch_bounds__(256) void mfma_ld_kernel(float* out, const float* wbuf, int iters) {
+    __shared__ float tile[64 * 34 + 8 * 4 * 200];
+    for (int i = threadIdx.x; i < 64 * 34 + 8 * 4 * 200; i += 256) tile[i] = 1e-9f * i;
+    __syncthreads();
+    f32x4 acc[4][3];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int lane = threadIdx.x & 63;
+    float b[3] = {1.0f, 1.0f + 1e-9f * blockIdx.x, 0.5f};
+    const int off_f = (lane >> 4) * 384 + (lane & 15) * 3 + (threadIdx.x >> 6) * 48;
+    const float* pb = wbuf + off_f;
+    const unsigned voff = off_f * 4u;
+    i32x4 srd;
+    srd[0] = (int)(unsigned)(unsigned long long)wbuf;
+    srd[1] = (int)(unsigned)((unsigned long long)wbuf >> 32);
+    srd[2] = 1 << 18;      // bytes
+    srd[3] = 0x00020000;   // raw buffer, dword format
+    const float* lb = tile + 64 * 34 + (lane >> 4) * 200 + (lane & 15) * 3 + (threadIdx.x >> 6) * 48;
+    f32x3 wv[8];
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (LD == 0 || LD == 2 || LD >= 3) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                float a = tile[(m * 16 + (lane & 15)) * 34 + k * 4 + (lane >> 4)];
+#pragma unroll
+                for (int n = 0; n < 3; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[n], acc[m][n], 0, 0, 0);
+            }
+            if (LD == 0 || LD == 1)
+                asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(wv[k]) : "v"(pb + k * 4 * 384) : "memory");
+            if (LD == 3)
+                asm volatile("global_load_dwordx3 %0, %1, %2" : "=v"(wv[k]) : "v"(voff + k * 4 * 384 * 4), "s"(wbuf) : "memory");
+            if (LD == 4) asm volatile("global_load_dword %0, %1, off" : "=v"(wv[k][0]) : "v"(pb + k * 4 * 384) : "memory");
+            if (LD == 5)
+                asm volatile("buffer_load_dwordx3 %0, %1, %2, 0 offen" : "=v"(wv[k]) : "v"(voff + k * 4 * 384 * 4), "s"(srd) : "memory");
+            if (LD == 6) {
+                wv[k][0] = lb[k * 4 * 200];
+                wv[k][1] = lb[k * 4 * 200 + 1];
+                wv[k][2] = lb[k * 4 * 200 + 2];
+            }
+        }
+        if (LD == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" ::"v"(wv[0]), "v"(wv[1]), "v"(wv[2]), "v"(wv[3]), "v"(wv[4]), "v"(wv[5]), "v"(wv[6]), "v"(wv[7]));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float s = 0.f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) s += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
+    if (s == 123.456f) out[0] = s;
+}
+
 extern "C" {
+long long mfma_ld_launch(int ld, int blocks, int iters, float* out, const float* wbuf, hipStream_t stream) {
+#define LDK(M) case M: hipLaunchKernelGGL(mfma_ld_kernel<M>, dim3(blocks), dim3(256), 0, stream, out, wbuf, iters); break;
+    switch (ld) {
+        LDK(0) LDK(1) LDK(2) LDK(3) LDK(4) LDK(5) LDK(6)
+        default: return -1;
+    }
+#undef LDK
+    return 8LL * 12 * iters;
+}
+long long mfma_mix_launch(int mode, int blocks, int iters, float* out, const float* wbuf, const float* big, long long big_rows,
+                          hipStream_t stream) {
+#define MIX(M) case M: hipLaunchKernelGGL(mfma_mix_kernel<M>, dim3(blocks), dim3(256), 0, stream, out, wbuf, big, big_rows, iters); break;
+    switch (mode) {
+        MIX(0) MIX(1) MIX(2) MIX(3) MIX(4) MIX(16) MIX(19) MIX(23)
+        default: return -1;
+    }
+#undef MIX
+    return 8LL * 12 * iters;
+}
+
 // variant 0: register-only, 12 accumulators; 1: A through LDS, 4x3 accumulators.  Returns matrix ops per wave per launch.
 long long mfma_probe_launch(int variant, int blocks, int iters, float* out, hipStream_t stream) {
     if (variant == 0) {

@@ -53,7 +53,7 @@ def timed(seconds, launch, flop_per_launch):
 
 
 def main():
-    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 3.0
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else 3.0
     dev = torch.device("cuda:0")
     lib = build()
     out = torch.zeros(16, device=dev)
@@ -70,6 +70,42 @@ def main():
             tf_tail, tf_head, state, n = timed(seconds, launch, flop)
             print(f"mfma 16x16x4 f32, {name}, {waves} wave(s)/SIMD: settled {tf_tail:6.1f} TFLOP/s "
                   f"(first quarter {tf_head:6.1f}; {n} launches) = {tf_tail / 157.3:.3f} of 157.3 | {state}", flush=True)
+    # the same LDS-fed loop with one more instruction class at a time (tools/mfma_probe.hip, mfma_mix_kernel)
+    lib.mfma_mix_launch.restype = ctypes.c_longlong
+    lib.mfma_mix_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_longlong, ctypes.c_void_p]
+    wbuf = torch.randn(1 << 16, device=dev)
+    rows = 1 << 18
+    big = torch.randn(rows, 384, device=dev)
+    names = {0: "nothing added", 1: "+ weight reload (1 dwordx3 / k-step, cache-resident)", 2: "+ gathers (2 dwordx4 / step, 8 lanes per random row)",
+             3: "+ weight reloads + gathers", 4: "+ 2 64-bit VALU adds / k-step",
+             16: "+ 4 ds_write_b64 + barrier / step", 19: "+ reloads + gathers + LDS stores + barrier", 23: "+ all of them"}
+    for mode, name in names.items():
+        blocks, iters = 1024, 1000
+        ops = lib.mfma_mix_launch(mode, blocks, 1, out.data_ptr(), wbuf.data_ptr(), big.data_ptr(), rows, stream)
+        assert ops > 0
+        flop = ops * iters * blocks * 4 * 2048.0
+
+        def launch():
+            lib.mfma_mix_launch(mode, blocks, iters, out.data_ptr(), wbuf.data_ptr(), big.data_ptr(), rows, stream)
+        tf_tail, tf_head, state, n = timed(min(seconds, 2.0), launch, flop)
+        print(f"LDS-fed loop, 4 waves/SIMD, {name}: {tf_tail:6.1f} TFLOP/s = {tf_tail / 157.3:.3f}", flush=True)
+    lib.mfma_ld_launch.restype = ctypes.c_longlong
+    lib.mfma_ld_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    forms = {0: "global_load_dwordx3 v, v[64-bit address] + s_waitcnt vmcnt(7) per k-step", 1: "same load, drained once per step",
+             2: "the s_waitcnt alone (no loads)", 3: "global_load_dwordx3 v, v_offset, s[base]", 4: "global_load_dword (64-bit address)",
+             5: "buffer_load_dwordx3 offen", 6: "three ds_read_b32 from LDS instead"}
+    for ld, name in forms.items():
+        blocks, iters = 1024, 1000
+        ops = lib.mfma_ld_launch(ld, blocks, 1, out.data_ptr(), wbuf.data_ptr(), stream)
+        assert ops > 0
+        flop = ops * iters * blocks * 4 * 2048.0
+
+        def launch():
+            lib.mfma_ld_launch(ld, blocks, iters, out.data_ptr(), wbuf.data_ptr(), stream)
+        tf_tail, tf_head, state, n = timed(min(seconds, 2.0), launch, flop)
+        print(f"LDS-fed loop + one load per k-step as {name}: {tf_tail:6.1f} TFLOP/s = {tf_tail / 157.3:.3f}", flush=True)
+    if "--mix-only" in sys.argv:
+        return
     torch.backends.cuda.matmul.allow_tf32 = False
     for m in (4096, 8192):
         a = torch.randn(m, m, device=dev); b = torch.randn(m, m, device=dev); c = torch.empty(m, m, device=dev)
