@@ -239,6 +239,27 @@ int sv_ball_query(const float* xyz, const float* new_xyz, int B, int N, int S, d
 int sv_three_nn_interpolate(const float* xyz1, const float* xyz2, const float* points2, int B, int N, int S, int C,
                             float* out, sv_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * N4  largest single-linkage cluster of the end-effector points
+ *   (replaces utils/output.py:13-28 ClusterUtil.get_largest_cluster = sklearn AgglomerativeClustering(
+ *    linkage="single", distance_threshold=0.06) + most frequent label; call site app/inference_engine.py:422-433)
+ *
+ * Single linkage cut at `dist` = connected components of the graph "distance < dist" (strict, as sklearn merges while
+ * the linkage distance is below the threshold).  Points: rows idx[i] (idx NULL = row i) of xyz, float32 or float64
+ * (elem_bytes 4 / 8), row stride ld elements; distance in float64: sqrt((dx*dx + dy*dy) + dz*dz), no fma.
+ *   root[i]  = the smallest i' in i's component (i, i' positions 0..n-1): a deterministic labelling
+ *   best[0]  = root of the largest component (ties: the smallest root), best[1] = its size   (best may be NULL)
+ * Lock-free union-find over all n(n-1)/2 pairs, tiled through LDS.  workspace: sv_cluster_workspace_bytes(n).
+ * ------------------------------------------------------------------------------------------- */
+size_t sv_cluster_workspace_bytes(int64_t n);
+int sv_single_linkage_roots(const void* xyz, int elem_bytes, int64_t ld, const int32_t* idx, int64_t n, double dist,
+                            void* workspace, size_t workspace_bytes, int32_t* root, int32_t* best, sv_stream_t stream);
+/* out = the ascending positions i with v[i] == value (v int32 / int64 by elem_bytes; value_dev non-NULL: compare with
+ * the int32 it points to on the device instead of `value`), count[0] = how many.  The np.where(...)[0] of
+ * utils/output.py:24 and app/inference_engine.py:420 without a host round trip. */
+int sv_select_equal(const void* v, int elem_bytes, int64_t n, int64_t value, const int32_t* value_dev, int64_t* out,
+                    int64_t* count, sv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

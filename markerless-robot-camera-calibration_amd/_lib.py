@@ -62,6 +62,9 @@ SIGNATURES = {
                                    _P]),
     "sv_fps": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
     "sv_three_nn_interpolate": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "sv_cluster_workspace_bytes": (c_size_t, [c_int64]),
+    "sv_single_linkage_roots": (c_int, [_P, c_int, c_int64, _P, c_int64, c_double, _P, c_size_t, _P, _P, _P]),
+    "sv_select_equal": (c_int, [_P, c_int, c_int64, c_int64, _P, _P, _P, _P]),
     "sv_ball_query": (c_int, [_P, _P, c_int, c_int, c_int, c_double, c_int, _P, _P]),
 }
 

@@ -126,14 +126,17 @@ class InferenceEngine:
             field = self._field(points, rgb, cfg.INFERENCE.SEGMENTATION.scale)
             out = self._segmentation_model(field.sparse())
             label, _ = out.slice_argmax(field, with_conf=False)
-        seg_results = label.cpu().numpy()
-        ee_mask = seg_results == 2
-        ee_idx = np.where(ee_mask)[0]
-        seg_results[ee_idx] = 1  # initially, all EE predictions become arm
-        if len(ee_idx) > 1:
-            inside = self.cluster_util.get_largest_cluster(np.asarray(points)[ee_mask])
-            seg_results[ee_idx[inside]] = 2  # EE = largest single-linkage cluster
-        return seg_results
+            # :419-433 on the device: EE predictions -> arm, except the largest single-linkage cluster among them
+            ee_idx = out_utils.select_equal(label, 2)
+            if ee_idx.numel() > 1:
+                pts = np.asarray(points)
+                xyz = torch.as_tensor(pts if pts.dtype in (np.float32, np.float64) else pts.astype(np.float64)).to(self.device)
+                inside = self.cluster_util.get_largest_cluster(xyz, idx=ee_idx)
+                label[ee_idx] = 1
+                label[ee_idx[inside]] = 2
+            elif ee_idx.numel() == 1:
+                label[ee_idx] = 1
+        return label.cpu().numpy()
 
     def predict_rotation(self, ee_raw_points, ee_rgb):
         cfg = self._config

@@ -37,11 +37,57 @@ def get_pred_center(out, coords, ee_r=0.03, q=None):
     return pred_center
 
 
+def select_equal(values, value):
+    """ascending positions i with values[i] == value, on the device (np.where(values == value)[0] of
+    utils/output.py:24 / app/inference_engine.py:420 without the host round trip).  values: int32 / int64 CUDA tensor;
+    value: python int or a 1-element int32 CUDA tensor."""
+    from ctypes import c_int, c_int64
+
+    from .._lib import call, ptr, stream_ptr
+
+    v = values.contiguous()
+    if v.dtype not in (torch.int32, torch.int64):
+        raise TypeError("select_equal: int32 or int64 values")
+    n = v.numel()
+    out = torch.empty(n, dtype=torch.int64, device=v.device)
+    count = torch.empty(1, dtype=torch.int64, device=v.device)
+    on_dev = torch.is_tensor(value)
+    call("sv_select_equal", ptr(v), c_int(v.element_size()), c_int64(n), c_int64(0 if on_dev else int(value)),
+         ptr(value) if on_dev else None, ptr(out), ptr(count), stream_ptr())
+    return out[: int(count.item())]
+
+
+def single_linkage_roots(points, dist, idx=None):
+    """Connected components of "distance < dist" among the rows idx (None = all) of a CUDA [*, >=3] float32 / float64
+    tensor: (root int32[n] = smallest member position of each point's component, best int32[2] = root and size of the
+    largest component) - sv_single_linkage_roots."""
+    from ctypes import c_double, c_int, c_int64, c_size_t
+
+    from .._lib import call, load, ptr, stream_ptr
+
+    if points.dtype not in (torch.float32, torch.float64) or points.stride(1) != 1:
+        points = points.to(torch.float32).contiguous()
+    n = int(points.shape[0] if idx is None else idx.numel())
+    if idx is not None:
+        idx = idx.to(torch.int32).contiguous()
+    root = torch.empty(n, dtype=torch.int32, device=points.device)
+    best = torch.zeros(2, dtype=torch.int32, device=points.device)
+    nbytes = load().sv_cluster_workspace_bytes(c_int64(n))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=points.device)
+    call("sv_single_linkage_roots", ptr(points), c_int(points.element_size()), c_int64(points.stride(0)), ptr(idx),
+         c_int64(n), c_double(float(dist)), ptr(ws), c_size_t(nbytes), ptr(root), ptr(best), stream_ptr())
+    return root, best
+
+
 class ClusterUtil:
     """Largest single-linkage cluster of the end-effector points (utils/output.py:13-28: sklearn
     AgglomerativeClustering(distance_threshold=0.06, linkage='single')).  Single linkage with a distance threshold
-    is exactly the connected components of the graph "distance < threshold"; computed on the host with a k-d tree
-    instead of sklearn's O(n^2) linkage matrix (stays a CPU step)."""
+    is exactly the connected components of the graph "distance < threshold".  CUDA tensors take the device path
+    (lock-free union-find over all pairs, csrc/sv_cluster.hip: 4 096 points in well under a millisecond where the
+    reference's linkage - and this class's host path - take hundreds); numpy inputs keep the host path (k-d tree +
+    scipy connected components), which the tests pin against sklearn itself.  Equal-size clusters: the reference takes
+    whichever label np.unique lists first (sklearn's numbering, arbitrary); both paths here take the cluster that
+    contains the lowest point index."""
 
     def __init__(self, dist=0.06, linkage="single"):
         if linkage != "single":
@@ -62,7 +108,16 @@ class ClusterUtil:
         g = coo_matrix((np.ones(len(pairs)), (pairs[:, 0], pairs[:, 1])), shape=(n, n))
         return connected_components(g, directed=False)[1]
 
-    def get_largest_cluster(self, points):
+    def get_largest_cluster(self, points, idx=None):
+        """positions (ascending) of the largest cluster's members.  CUDA tensor in -> int64 CUDA tensor out; idx
+        (device path only) restricts the points to those rows, positions then refer to idx."""
+        if torch.is_tensor(points) and points.is_cuda:
+            n = int(points.shape[0] if idx is None else idx.numel())
+            if n == 0:
+                return torch.empty(0, dtype=torch.int64, device=points.device)
+            root, best = single_linkage_roots(points, self.dist, idx)
+            return select_equal(root, best[:1])
         labels = self.labels(points)
+        # scipy numbers components by their first member, so the first maximum is the cluster with the lowest index
         unique, counts = np.unique(labels, return_counts=True)
         return np.where(labels == unique[counts.argmax()])[0]

@@ -641,3 +641,40 @@ def icp_point2point(src, tgt, init_T=None, max_distance=0.1, max_iterations=30, 
         T = U @ T
         updates += 1
     return T, fitness, rmse, updates
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# N4: largest single-linkage cluster (utils/output.py:13-28 ClusterUtil.get_largest_cluster; app/inference_engine.py:422-433)
+# ------------------------------------------------------------------------------------------------------------------
+def single_linkage_roots(points, dist=0.06):
+    """sklearn AgglomerativeClustering(linkage="single", distance_threshold=dist) merges while the linkage distance is
+    below dist, i.e. its clusters are the connected components of the graph "distance < dist".  Restated as a plain
+    O(n^2) flood fill in float64 (distance = sqrt((dx*dx + dy*dy) + dz*dz)); root[i] = the smallest member of i's
+    component.  Pinned against sklearn itself in tests/test_cluster_cpu.py."""
+    pts = np.asarray(points, dtype=np.float64)
+    n = len(pts)
+    root = np.full(n, -1, dtype=np.int64)
+    for s in range(n):
+        if root[s] >= 0:
+            continue
+        root[s] = s
+        stack = [s]
+        while stack:
+            i = stack.pop()
+            d = pts - pts[i]
+            near = np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]) < dist
+            new = np.where(near & (root < 0))[0]
+            root[new] = s
+            stack.extend(new.tolist())
+    return root
+
+
+def largest_cluster(points, dist=0.06):
+    """positions (ascending) of the largest component; equal sizes: the one containing the lowest index (the reference
+    takes whichever label sklearn happens to number first - arbitrary)."""
+    root = single_linkage_roots(points, dist)
+    if len(root) == 0:
+        return np.zeros(0, dtype=np.int64)
+    u, c = np.unique(root, return_counts=True)
+    return np.where(root == u[c.argmax()])[0]
+
