@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void mfma_lds_kernel(float* out, int iters) {
 // k-step, 16 = four ds_write_b64 + barrier per 8 k-steps.  Waits as in conv_tile_body: a k-step waits for the weight row
 // requested 8 k-steps earlier (s_waitcnt vmcnt(7)), the end of a step for its two gathers.  Loaded values are never read.
 typedef float f32x3 __attribute__((ext_vector_type(3)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 template <int MODE>
 __global__ __launch_bounds__(256) void mfma_mix_kernel(float* out, const float* wbuf, const float* big, long long big_rows,
                                                        int iters) {
@@ -85,8 +86,29 @@ __global__ __launch_bounds__(256) void mfma_mix_kernel(float* out, const float* 
     // compiler has meanwhile given to an address)
     f32x4 gv[2];
     f32x3 wv[8];
+    // MODE & 32: the same loads in buffer form (descriptor + 32-bit offsets; gather offsets from an LDS table)
+    __shared__ unsigned row_off[64 * 32];
+    i32x4 srd_w, srd_big;
+    srd_w[0] = (int)(unsigned)(unsigned long long)wbuf; srd_w[1] = (int)(unsigned)((unsigned long long)wbuf >> 32);
+    srd_w[2] = 1 << 18; srd_w[3] = 0x00020000;
+    srd_big[0] = (int)(unsigned)(unsigned long long)big; srd_big[1] = (int)(unsigned)((unsigned long long)big >> 32);
+    srd_big[2] = (int)(big_rows * 1536); srd_big[3] = 0x00020000;
+    if (MODE & 32) {
+        for (int e = threadIdx.x; e < 64 * 32; e += 256) {
+            rnd = rnd * 6364136223846793005ull + 1442695040888963407ull;
+            row_off[e] = (unsigned)(((rnd >> 20) % (unsigned long long)big_rows) * 1536ull);
+        }
+        __syncthreads();
+    }
+    const unsigned wv_off = (unsigned)((lane >> 4) * 384 + (lane & 15) * 3 + (threadIdx.x >> 6) * 48) * 4u;
     for (int i = 0; i < iters; ++i) {
-        if (MODE & 2) {
+        if ((MODE & 34) == 34) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const unsigned vo = row_off[((i * 2 + g) & 63) * 32 + (threadIdx.x >> 3)] + (threadIdx.x & 7) * 16u;
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(gv[g]) : "v"(vo), "s"(srd_big) : "memory");
+            }
+        } else if (MODE & 2) {
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 rnd = rnd * 6364136223846793005ull + 1442695040888963407ull;
@@ -103,7 +125,9 @@ __global__ __launch_bounds__(256) void mfma_mix_kernel(float* out, const float* 
 #pragma unroll
                 for (int n = 0; n < 3; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[n], acc[m][n], 0, 0, 0);
             }
-            if (MODE & 1) {
+            if ((MODE & 33) == 33) {
+                asm volatile("buffer_load_dwordx3 %0, %1, %2, %3 offen" : "=v"(wv[k]) : "v"(wv_off), "s"(srd_w), "s"(k * 4 * 384 * 4) : "memory");
+            } else if (MODE & 1) {
                 asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(wv[k]) : "v"(pb + k * 4 * 384) : "memory");
             }
             if (MODE & 4) {
@@ -138,7 +162,6 @@ __global__ __launch_bounds__(256) void mfma_mix_kernel(float* out, const float* 
 // (LD): 0 = global_load_dwordx3 v, v[addr 64-bit], off + s_waitcnt vmcnt(7) per k-step; 1 = same load, no wait in the
 // loop (drain per step); 2 = the waits without the loads; 3 = global_load_dwordx3 v, v_offset, s[base]; 4 = dword
 // instead of dwordx3; 5 = buffer_load_dwordx3 (resource descriptor + 32-bit offset); 6 = ds_read_b96 from LDS.
-typedef int i32x4 __attribute__((ext_vector_type(4)));
 template <int LD>
 __global__ __launch_bounds__(256) void mfma_ld_kernel(float* out, const float* wbuf, int iters) {
     __shared__ float tile[64 * 34 + 8 * 4 * 200];
@@ -210,7 +233,7 @@ long long mfma_mix_launch(int mode, int blocks, int iters, float* out, const flo
                           hipStream_t stream) {
 #define MIX(M) case M: hipLaunchKernelGGL(mfma_mix_kernel<M>, dim3(blocks), dim3(256), 0, stream, out, wbuf, big, big_rows, iters); break;
     switch (mode) {
-        MIX(0) MIX(1) MIX(2) MIX(3) MIX(4) MIX(16) MIX(19) MIX(23)
+        MIX(0) MIX(1) MIX(2) MIX(3) MIX(4) MIX(16) MIX(19) MIX(23) MIX(33) MIX(34) MIX(35) MIX(51)
         default: return -1;
     }
 #undef MIX

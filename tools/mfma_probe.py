@@ -78,7 +78,10 @@ def main():
     big = torch.randn(rows, 384, device=dev)
     names = {0: "nothing added", 1: "+ weight reload (1 dwordx3 / k-step, cache-resident)", 2: "+ gathers (2 dwordx4 / step, 8 lanes per random row)",
              3: "+ weight reloads + gathers", 4: "+ 2 64-bit VALU adds / k-step",
-             16: "+ 4 ds_write_b64 + barrier / step", 19: "+ reloads + gathers + LDS stores + barrier", 23: "+ all of them"}
+             16: "+ 4 ds_write_b64 + barrier / step", 19: "+ reloads + gathers + LDS stores + barrier", 23: "+ all of them",
+             33: "+ weight reload as buffer_load (SGPR row offset, constant VGPR offset)",
+             34: "+ gathers as buffer_load (offsets from an LDS table + 1 v_add)", 35: "+ both in buffer form",
+             51: "+ both in buffer form + LDS stores + barrier (the kernel's step)"}
     for mode, name in names.items():
         blocks, iters = 1024, 1000
         ops = lib.mfma_mix_launch(mode, blocks, 1, out.data_ptr(), wbuf.data_ptr(), big.data_ptr(), rows, stream)
