@@ -200,15 +200,38 @@ __device__ __forceinline__ void conv_tile_body(const ConvParams& p, const int bi
     const int nsub = rem >= TM_ ? SUBS : (int)((rem + 15) / 16);
     dense_mask = (1u << nsub) - 1u;
   }
-  for (int e = tid; e < K * TM_; e += 256) {
-    const int k = e / TM_, r = e - k * TM_;
-    int n;
-    if (p.nbr_s)
-      n = p.nbr_s[(int64_t)k * p.Vpad + row0 + r];
-    else
-      n = (row0 + r < p.V_out) ? (int)(row0 + r) : -1;
-    // FAST: the table holds the row's BYTE offset in `in` (absent: beyond the buffer's extent -> the load returns 0)
-    idx_s[e] = FAST ? (int)(n >= 0 ? (uint32_t)n * (uint32_t)(p.in_ld * 4) : BUF_ABSENT) : n;
+  if constexpr (FAST) {
+    // all of the thread's table entries are requested before the first is used (a rolled loop waits for each load in
+    // turn); the table holds each row's BYTE offset in `in` (absent: beyond the buffer's extent -> zeros)
+    constexpr int STAGE_IT = (32 * TM_ + 255) / 256;  // K <= 32
+    int n_st[STAGE_IT];
+#pragma unroll
+    for (int it = 0; it < STAGE_IT; ++it) {
+      const int e = tid + 256 * it;
+      const int k = e / TM_, r = e % TM_;
+      n_st[it] = -1;
+      if (e < K * TM_) {
+        if (p.nbr_s)
+          n_st[it] = p.nbr_s[(int64_t)k * p.Vpad + row0 + r];
+        else
+          n_st[it] = (row0 + r < p.V_out) ? (int)(row0 + r) : -1;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < STAGE_IT; ++it) {
+      const int e = tid + 256 * it;
+      if (e < K * TM_) idx_s[e] = (int)(n_st[it] >= 0 ? (uint32_t)n_st[it] * (uint32_t)(p.in_ld * 4) : BUF_ABSENT);
+    }
+  } else {
+    for (int e = tid; e < K * TM_; e += 256) {
+      const int k = e / TM_, r = e - k * TM_;
+      int n;
+      if (p.nbr_s)
+        n = p.nbr_s[(int64_t)k * p.Vpad + row0 + r];
+      else
+        n = (row0 + r < p.V_out) ? (int)(row0 + r) : -1;
+      idx_s[e] = n;
+    }
   }
   const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)p.w_bytes, 0x00020000);
