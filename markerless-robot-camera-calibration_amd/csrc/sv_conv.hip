@@ -587,44 +587,65 @@ __device__ __forceinline__ void conv_tile_body(const ConvParams& p, const int bi
         for (int reg = 0; reg < 4; ++reg) o[s][reg] = (r + reg < p.V_out) ? (int)(r + reg) : -1;
       }
     }
+    // The arithmetic is unconditional: absent BN / bias / residual become operands that change no bit of any value
+    // (fmaf(x, 1, -0) == x and x + (-0) == x for every x, signed zeros and NaN included; bias alone: fmaf(x, 1, b) is
+    // the one rounding of x + b), and the activation is chosen ONCE, outside the unrolled element loops.  (With the
+    // three run-time switches tested per element the 48 elements of a lane were ~150 scalar branches: 22 us from the
+    // end of the loop to the last store of a 64-row workgroup, 7 us of a 16-row one - per-phase stamps of a trace build.)
+    float scf[NT], shf[NT];
 #pragma unroll
-    for (int s = 0; s < MR; ++s) {
-      yvec_t res[4];
-      if (p.residual) {
+    for (int n = 0; n < NT; ++n) {
+      scf[n] = p.scale ? sc[n] : 1.0f;
+      shf[n] = p.scale ? sh[n] : (p.shift ? sh[n] : -0.0f);
+    }
+    const float slope = p.slope;
+    auto finish = [&](auto act_tag) {
+      constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+      for (int s = 0; s < MR; ++s) {
+        yvec_t res[4];
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg)
-          res[reg] = buffer_load_floats<NT>(
-              rsrc_res, o[s][reg] >= 0 ? (uint32_t)o[s][reg] * (uint32_t)(p.res_ld * 4) + (uint32_t)col0 * 4u : BUF_ABSENT, 0u);
-      }
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        yvec_t y;
+          for (int n = 0; n < NT; ++n) res[reg][n] = -0.0f;
+        if (p.residual) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          float v = acc[s][n][reg];
-          if (p.scale)
-            v = __builtin_fmaf(v, sc[n], sh[n]);
-          else if (p.shift)
-            v = v + sh[n];
-          if (p.residual) v = v + res[reg][n];
-          if (p.act == SV_ACT_RELU)
-            v = v < 0.f ? 0.f : v;  // NaN stays NaN, as torch.relu
-          else if (p.act == SV_ACT_LEAKY_RELU)
-            v = v > 0.f ? v : v * p.slope;
-          y[n] = v;
+          for (int reg = 0; reg < 4; ++reg)
+            res[reg] = buffer_load_floats<NT>(
+                rsrc_res, o[s][reg] >= 0 ? (uint32_t)o[s][reg] * (uint32_t)(p.res_ld * 4) + (uint32_t)col0 * 4u : BUF_ABSENT,
+                0u);
         }
-        const uint32_t off =
-            o[s][reg] >= 0 ? (uint32_t)o[s][reg] * (uint32_t)(p.out_ld * 4) + (uint32_t)col0 * 4u : BUF_ABSENT;
-        if constexpr (NT == 1)
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, y[0]), rsrc_out, off, 0, 0);
-        else if constexpr (NT == 2)
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2_t, y), rsrc_out, off, 0, 0);
-        else if constexpr (NT == 3)
-          __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(i32x3_t, y), rsrc_out, off, 0, 0);
-        else
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, y), rsrc_out, off, 0, 0);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          yvec_t y;
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            float v = __builtin_fmaf(acc[s][n][reg], scf[n], shf[n]) + res[reg][n];
+            if constexpr (ACT == SV_ACT_RELU)
+              v = v < 0.f ? 0.f : v;  // NaN stays NaN, as torch.relu
+            else if constexpr (ACT == SV_ACT_LEAKY_RELU)
+              v = v > 0.f ? v : v * slope;
+            y[n] = v;
+          }
+          const uint32_t off =
+              o[s][reg] >= 0 ? (uint32_t)o[s][reg] * (uint32_t)(p.out_ld * 4) + (uint32_t)col0 * 4u : BUF_ABSENT;
+          if constexpr (NT == 1)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, y[0]), rsrc_out, off, 0, 0);
+          else if constexpr (NT == 2)
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2_t, y), rsrc_out, off, 0, 0);
+          else if constexpr (NT == 3)
+            __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(i32x3_t, y), rsrc_out, off, 0, 0);
+          else
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, y), rsrc_out, off, 0, 0);
+        }
       }
-    }
+    };
+    if (p.act == SV_ACT_RELU)
+      finish(std::integral_constant<int, SV_ACT_RELU>{});
+    else if (p.act == SV_ACT_LEAKY_RELU)
+      finish(std::integral_constant<int, SV_ACT_LEAKY_RELU>{});
+    else
+      finish(std::integral_constant<int, SV_ACT_NONE>{});
   } else
 #pragma unroll
   for (int s = 0; s < MR; ++s) {
