@@ -221,3 +221,37 @@ def test_thin_wave_per_subtile_kernel_strided_and_batched(gpu, oracle):
     xc = rng.normal(size=(Vc, 32)).astype(np.float32)
     got = svnn.conv_forward(t(xc), t(W8), cm.plan_up(2), V).cpu().numpy()
     assert np.array_equal(got, oracle.conv(xc, W8, frame.kup(2), V))
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 64), (96, 384)])
+def test_epilogue_every_combination_same_bits(gpu, oracle, cin, cout):
+    """BN scale / bias / residual present or absent x the three activations through the branch-free epilogue of the
+    buffer-addressed instances: absent operands are replaced by values that must change no bit (fmaf(x, 1, -0),
+    x + (-0)), so the comparison is on the BIT PATTERNS (signed zeros included), with zero rows and exact
+    cancellations in the input to produce both zeros."""
+    from mrcc_amd import nn as svnn
+
+    ME, field, st, coords4 = _setup(gpu, n=6000, L=0.6, seed=3)
+    frame = oracle.Frame(oracle.voxelize(coords4)["coords"])
+    V = st.F.shape[0]
+    rng = np.random.default_rng(cin + cout)
+    x = rng.normal(size=(V, cin)).astype(np.float32)
+    x[rng.random(V) < 0.2] = 0.0                      # rows of zeros: accumulators stay +0
+    W = (rng.normal(size=(27, cin, cout)) * np.sqrt(2.0 / (27 * cout))).astype(np.float32)
+    scale = rng.uniform(-1.5, 1.5, size=cout).astype(np.float32)   # negative scales: -0 products
+    shift = rng.normal(size=cout).astype(np.float32)
+    shift[::3] = 0.0
+    res = rng.normal(size=(V, cout)).astype(np.float32)
+    res[rng.random(V) < 0.3] = -0.0
+    plan = st.coordinate_manager.plan_k3(1)
+    t = lambda a: torch.from_numpy(a).to(gpu) if a is not None else None
+    for use_scale in (False, True):
+        for use_shift in (False, True):
+            for use_res in (False, True):
+                for act in (oracle.ACT_NONE, oracle.ACT_RELU, oracle.ACT_LEAKY):
+                    sc, sh, rs = (scale if use_scale else None), (shift if use_shift else None), (res if use_res else None)
+                    got = svnn.conv_forward(t(x), t(W), plan, V, t(sc), t(sh), t(rs), act, 0.01).cpu().numpy()
+                    want = oracle.conv(x, W, frame.k3(1), V, sc, sh, rs, act, 0.01)
+                    same = np.array_equal(got.view(np.int32), want.view(np.int32))
+                    assert same, (use_scale, use_shift, use_res, act,
+                                  int((got.view(np.int32) != want.view(np.int32)).sum()), np.abs(got - want).max())
