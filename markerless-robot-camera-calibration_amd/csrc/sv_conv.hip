@@ -141,6 +141,98 @@ struct ConvCfg {
   static constexpr size_t lds_bytes(int K) { return (size_t)(2 * TM_ * SA + K * TM_) * sizeof(float); }
 };
 
+// ---- epilogue of the buffer-addressed kernels: BN(eval) / bias -> residual -> activation -> store by `perm`.
+//      acc[s][n][reg]: C/D map of the matrix op, column = lane & 15 of column tile n (output channel col0 + n), row =
+//      rows0 + 16 s + 4 lq + reg of the plan.
+template <int MR, int NT>
+__device__ __forceinline__ void epilogue_buffered(const ConvParams& p, const f32x4 (&acc)[MR][NT], const int64_t rows0,
+                                                  const int lq, const int col0) {
+  // branch-free: the 4 consecutive output rows a lane holds per sub-tile come from ONE int4 load of `perm`, all MR of
+  // them requested up front; a sub-tile's residual rows are requested together; rows past V_out (perm < 0) get a
+  // byte offset beyond the extents, so their residual loads return zeros and their stores are dropped by the
+  // descriptor's range check.  (With a branch per row and per column the epilogue was a chain of dependent round
+  // trips - 31 us of a 770 us workgroup on the 64-row tile; this form: dense layers +4-5 %, the level-0 launch and
+  // the frame rate +1.2 %.)
+  typedef float yvec_t __attribute__((ext_vector_type(NT)));
+  const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)p.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_res =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, p.residual ? (int)p.res_bytes : 0, 0x00020000);
+  int o[MR][4];
+#pragma unroll
+  for (int s = 0; s < MR; ++s) {
+    const int64_t r = rows0 + s * 16 + lq * 4;
+    if (p.perm) {
+      const int4 o4 = *(const int4*)(p.perm + r);
+      o[s][0] = o4.x;
+      o[s][1] = o4.y;
+      o[s][2] = o4.z;
+      o[s][3] = o4.w;
+    } else {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) o[s][reg] = (r + reg < p.V_out) ? (int)(r + reg) : -1;
+    }
+  }
+  // The arithmetic is unconditional: absent BN / bias / residual become operands that change no bit of any value
+  // (fmaf(x, 1, -0) == x and x + (-0) == x for every x, signed zeros and NaN included; bias alone: fmaf(x, 1, b) is
+  // the one rounding of x + b), and the activation is chosen ONCE, outside the unrolled element loops.  (With the
+  // three run-time switches tested per element the 48 elements of a lane were ~150 scalar branches: 22 us from the
+  // end of the loop to the last store of a 64-row workgroup, 7 us of a 16-row one - per-phase stamps of a trace build.)
+  float scf[NT], shf[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    scf[n] = p.scale ? p.scale[col0 + n] : 1.0f;
+    shf[n] = p.shift ? p.shift[col0 + n] : (p.scale ? 0.0f : -0.0f);
+  }
+  const float slope = p.slope;
+  auto finish = [&](auto act_tag) {
+    constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+    for (int s = 0; s < MR; ++s) {
+      yvec_t res[4];
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) res[reg][n] = -0.0f;
+      if (p.residual) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+          res[reg] = buffer_load_floats<NT>(
+              rsrc_res, o[s][reg] >= 0 ? (uint32_t)o[s][reg] * (uint32_t)(p.res_ld * 4) + (uint32_t)col0 * 4u : BUF_ABSENT,
+              0u);
+      }
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        yvec_t y;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          float v = __builtin_fmaf(acc[s][n][reg], scf[n], shf[n]) + res[reg][n];
+          if constexpr (ACT == SV_ACT_RELU)
+            v = v < 0.f ? 0.f : v;  // NaN stays NaN, as torch.relu
+          else if constexpr (ACT == SV_ACT_LEAKY_RELU)
+            v = v > 0.f ? v : v * slope;
+          y[n] = v;
+        }
+        const uint32_t off =
+            o[s][reg] >= 0 ? (uint32_t)o[s][reg] * (uint32_t)(p.out_ld * 4) + (uint32_t)col0 * 4u : BUF_ABSENT;
+        if constexpr (NT == 1)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, y[0]), rsrc_out, off, 0, 0);
+        else if constexpr (NT == 2)
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2_t, y), rsrc_out, off, 0, 0);
+        else if constexpr (NT == 3)
+          __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(i32x3_t, y), rsrc_out, off, 0, 0);
+        else
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, y), rsrc_out, off, 0, 0);
+      }
+    }
+  };
+  if (p.act == SV_ACT_RELU)
+    finish(std::integral_constant<int, SV_ACT_RELU>{});
+  else if (p.act == SV_ACT_LEAKY_RELU)
+    finish(std::integral_constant<int, SV_ACT_LEAKY_RELU>{});
+  else
+    finish(std::integral_constant<int, SV_ACT_NONE>{});
+}
+
 // One pipeline step = (kernel offset k, input-channel chunk c0), visited in ascending (k, c0) order (CPO > 0: GK
 // consecutive offsets x all Cin channels per step).
 //   A (gathered rows, TM_ x KC): global -> registers one step ahead -> LDS (double buffered), one barrier per step.
@@ -562,90 +654,7 @@ __device__ __forceinline__ void conv_tile_body(const ConvParams& p, const int bi
     sh[n] = (p.shift && ok) ? p.shift[col0 + n] : 0.0f;
   }
   if constexpr (FAST) {
-    // branch-free: the 4 consecutive output rows a lane holds per sub-tile come from ONE int4 load of `perm`, all MR of
-    // them requested up front; a sub-tile's residual rows are requested together; rows past V_out (perm < 0) get a
-    // byte offset beyond the extents, so their residual loads return zeros and their stores are dropped by the
-    // descriptor's range check.  (With a branch per row and per column the epilogue was a chain of dependent round
-    // trips - 31 us of a 770 us workgroup on the 64-row tile; this form: dense layers +4-5 %, the level-0 launch and
-    // the frame rate +1.2 %.)
-    typedef float yvec_t __attribute__((ext_vector_type(NT)));
-    const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)p.out_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_res =
-        __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, p.residual ? (int)p.res_bytes : 0, 0x00020000);
-    int o[MR][4];
-#pragma unroll
-    for (int s = 0; s < MR; ++s) {
-      const int64_t r = row0 + wm * MR * 16 + s * 16 + lq * 4;
-      if (p.perm) {
-        const int4 o4 = *(const int4*)(p.perm + r);
-        o[s][0] = o4.x;
-        o[s][1] = o4.y;
-        o[s][2] = o4.z;
-        o[s][3] = o4.w;
-      } else {
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) o[s][reg] = (r + reg < p.V_out) ? (int)(r + reg) : -1;
-      }
-    }
-    // The arithmetic is unconditional: absent BN / bias / residual become operands that change no bit of any value
-    // (fmaf(x, 1, -0) == x and x + (-0) == x for every x, signed zeros and NaN included; bias alone: fmaf(x, 1, b) is
-    // the one rounding of x + b), and the activation is chosen ONCE, outside the unrolled element loops.  (With the
-    // three run-time switches tested per element the 48 elements of a lane were ~150 scalar branches: 22 us from the
-    // end of the loop to the last store of a 64-row workgroup, 7 us of a 16-row one - per-phase stamps of a trace build.)
-    float scf[NT], shf[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      scf[n] = p.scale ? sc[n] : 1.0f;
-      shf[n] = p.scale ? sh[n] : (p.shift ? sh[n] : -0.0f);
-    }
-    const float slope = p.slope;
-    auto finish = [&](auto act_tag) {
-      constexpr int ACT = decltype(act_tag)::value;
-#pragma unroll
-      for (int s = 0; s < MR; ++s) {
-        yvec_t res[4];
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg)
-#pragma unroll
-          for (int n = 0; n < NT; ++n) res[reg][n] = -0.0f;
-        if (p.residual) {
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg)
-            res[reg] = buffer_load_floats<NT>(
-                rsrc_res, o[s][reg] >= 0 ? (uint32_t)o[s][reg] * (uint32_t)(p.res_ld * 4) + (uint32_t)col0 * 4u : BUF_ABSENT,
-                0u);
-        }
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          yvec_t y;
-#pragma unroll
-          for (int n = 0; n < NT; ++n) {
-            float v = __builtin_fmaf(acc[s][n][reg], scf[n], shf[n]) + res[reg][n];
-            if constexpr (ACT == SV_ACT_RELU)
-              v = v < 0.f ? 0.f : v;  // NaN stays NaN, as torch.relu
-            else if constexpr (ACT == SV_ACT_LEAKY_RELU)
-              v = v > 0.f ? v : v * slope;
-            y[n] = v;
-          }
-          const uint32_t off =
-              o[s][reg] >= 0 ? (uint32_t)o[s][reg] * (uint32_t)(p.out_ld * 4) + (uint32_t)col0 * 4u : BUF_ABSENT;
-          if constexpr (NT == 1)
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, y[0]), rsrc_out, off, 0, 0);
-          else if constexpr (NT == 2)
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2_t, y), rsrc_out, off, 0, 0);
-          else if constexpr (NT == 3)
-            __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(i32x3_t, y), rsrc_out, off, 0, 0);
-          else
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, y), rsrc_out, off, 0, 0);
-        }
-      }
-    };
-    if (p.act == SV_ACT_RELU)
-      finish(std::integral_constant<int, SV_ACT_RELU>{});
-    else if (p.act == SV_ACT_LEAKY_RELU)
-      finish(std::integral_constant<int, SV_ACT_LEAKY_RELU>{});
-    else
-      finish(std::integral_constant<int, SV_ACT_NONE>{});
+    epilogue_buffered<MR, NT>(p, acc, row0 + wm * MR * 16, lq, col0);
   } else
 #pragma unroll
   for (int s = 0; s < MR; ++s) {
@@ -809,7 +818,6 @@ __global__ __launch_bounds__(256) void linear_narrow_kernel(ConvParams p) {
 //        * weights (wave-uniform per offset, 4 KB) come from L1/L2 one offset ahead.
 //      No LDS traffic for the features, no barrier, D gathers in flight per wave from its first microsecond on.
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-__device__ __attribute__((aligned(16))) float thin_zero_row[128];  // zero-initialised: the row an absent neighbour reads
 __device__ __forceinline__ void transpose4x4_lanegroups(float& r0, float& r1, float& r2, float& r3) {
   // in: lane group g (16 lanes) holds X[g][i] in r_i; out: lane group g holds X[i][g] in r_i
   u32x2_t a = __builtin_amdgcn_permlane32_swap(__float_as_uint(r0), __float_as_uint(r2), false, false);
@@ -831,7 +839,6 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvParams p) {
   // D: offsets in flight per wave (gather ring)
   static_assert(CIN % 16 == 0 && COUT % 16 == 0 && NT >= 1 && NT <= 4 && (MR == 1 || MR == 2), "shape");
   typedef float bvec_t __attribute__((ext_vector_type(NT)));
-  typedef float bvec_load_t __attribute__((ext_vector_type(NT), aligned(4)));
   __shared__ int idx_s[4][32 * 16 * MR];
   __shared__ int klist_s[4][32];
   const int lane = threadIdx.x & 63;
@@ -849,8 +856,26 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvParams p) {
   const unsigned long long amask = __ballot(active);
   const int nact = __popcll(amask);
   if (active) klist_s[wid][__popcll(amask & ((1ull << lane) - 1ull))] = lane;
-  for (int e = lane; e < K * ROWS; e += 64) idx_s[wid][e] = p.nbr_s[(int64_t)(e / ROWS) * p.Vpad + row0 + (e % ROWS)];
+  // the wave's neighbour table: all entries requested before the first is stored (a rolled loop is a chain of K / 4
+  // dependent round trips - a third of this kernel's life at level 1), kept as BYTE offsets of the rows in `in`
+  // (absent: beyond the extent, the gather then returns zeros)
+  {
+    constexpr int ST = 32 * ROWS / 64;  // K <= 32
+    int n_st[ST];
+#pragma unroll
+    for (int it = 0; it < ST; ++it) {
+      const int e = lane + 64 * it;
+      n_st[it] = e < K * ROWS ? p.nbr_s[(int64_t)(e / ROWS) * p.Vpad + row0 + (e % ROWS)] : -1;
+    }
+#pragma unroll
+    for (int it = 0; it < ST; ++it) {
+      const int e = lane + 64 * it;
+      if (e < K * ROWS) idx_s[wid][e] = (int)(n_st[it] >= 0 ? (uint32_t)n_st[it] * (uint32_t)(p.in_ld * 4) : BUF_ABSENT);
+    }
+  }
   __builtin_amdgcn_wave_barrier();  // same-wave LDS traffic is ordered; keep the compiler from moving reads above
+  const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)p.w_bytes, 0x00020000);
 
   f32x4 acc[MR][NT];
 #pragma unroll
@@ -859,8 +884,8 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvParams p) {
     for (int n = 0; n < NT; ++n) acc[s][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float4 g[D][MR][G4];
   bvec_t b[2][KS];
-  // Every load below is unconditional (slots past the end of the list re-read the last offset's weights and the zero
-  // row, their matrix ops then add fma(0, w, acc) = acc): the loop body is straight-line code, so hipcc can count its
+  // Every load below is unconditional (slots past the end of the list re-read the last offset's weights and read zeros
+  // through the range check, their matrix ops then add fma(0, w, acc) = acc): straight-line code, so hipcc can count its
   // s_waitcnt vmcnt instead of draining the ring at every control-flow merge.
   const int last = nact > 0 ? nact - 1 : 0;
   auto offset_of = [&](int j) { return __builtin_amdgcn_readfirstlane(klist_s[wid][min(j, last)]); };
@@ -868,19 +893,21 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvParams p) {
     const int k = offset_of(j);
 #pragma unroll
     for (int s = 0; s < MR; ++s) {
-      const int n = idx_s[wid][k * ROWS + s * 16 + li];
-      const bool ok = n >= 0 && j < nact;
-      // an absent neighbour reads a row of zeros: the load stays unconditional and needs no select behind it (with
-      // `ok ? value : 0` hipcc sinks the load under the condition and waits for it at the merge)
-      const float* src = (ok ? p.in + (int64_t)n * p.in_ld : thin_zero_row) + 4 * lq;
+      // an absent neighbour (and a ring slot past the end of the list) reads beyond the buffer's extent: zeros from the
+      // range check, no select behind the load (with `ok ? value : 0` hipcc sinks the load under the condition)
+      const uint32_t off = j < nact ? (uint32_t)idx_s[wid][k * ROWS + s * 16 + li] : BUF_ABSENT;
 #pragma unroll
-      for (int jj = 0; jj < G4; ++jj) dst[s][jj] = *(const float4*)(src + 16 * jj);
+      for (int jj = 0; jj < G4; ++jj) {
+        const f32x4 v = buffer_load_floats<4>(rsrc_in, off + 16u * (uint32_t)lq, 64u * (uint32_t)jj);
+        dst[s][jj] = make_float4(v[0], v[1], v[2], v[3]);
+      }
     }
   };
   auto load_w = [&](int j, bvec_t (&dst)[KS]) {
-    const float* wk = p.W + (int64_t)offset_of(j) * CIN * COUT + lq * COUT + NT * li;
+    const uint32_t wk = (uint32_t)offset_of(j) * (uint32_t)(CIN * COUT * 4);  // wave-uniform: the SGPR offset
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) dst[ks] = *(const bvec_load_t*)(wk + 4 * ks * COUT);
+    for (int ks = 0; ks < KS; ++ks)
+      dst[ks] = buffer_load_floats<NT>(rsrc_w, (uint32_t)(lq * COUT + NT * li) * 4u, wk + (uint32_t)(4 * ks * COUT * 4));
   };
   auto compute = [&](float4 (&a)[MR][G4], bvec_t (&w)[KS]) {
 #pragma unroll
@@ -915,47 +942,8 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvParams p) {
       }
     }
   }
-  // ---- epilogue (as conv_tile_body): C/D map: MFMA col = lane & 15, row = (lane >> 4) * 4 + reg
-  const int col0 = NT * li;
-  float sc[NT], sh[NT];
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    sc[n] = p.scale ? p.scale[col0 + n] : 1.0f;
-    sh[n] = p.shift ? p.shift[col0 + n] : 0.0f;
-  }
-#pragma unroll
-  for (int s = 0; s < MR; ++s) {
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int64_t o = p.perm[row0 + s * 16 + lq * 4 + reg];
-      if (o < 0) continue;
-      float y[NT];
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        float v = acc[s][n][reg];
-        if (p.scale)
-          v = __builtin_fmaf(v, sc[n], sh[n]);
-        else if (p.shift)
-          v = v + sh[n];
-        y[n] = v;
-      }
-      if (p.residual) {
-        const float* res = p.residual + o * p.res_ld + col0;
-#pragma unroll
-        for (int n = 0; n < NT; ++n) y[n] = y[n] + res[n];
-      }
-      float* dst = p.out + o * p.out_ld + col0;
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        float v = y[n];
-        if (p.act == SV_ACT_RELU)
-          v = v < 0.f ? 0.f : v;  // NaN stays NaN, as torch.relu
-        else if (p.act == SV_ACT_LEAKY_RELU)
-          v = v > 0.f ? v : v * p.slope;
-        dst[n] = v;
-      }
-    }
-  }
+  // ---- epilogue (shared with conv_tile_body): C/D map: MFMA col = lane & 15, row = (lane >> 4) * 4 + reg
+  epilogue_buffered<MR, NT>(p, acc, row0, lq, NT * li);
 }
 
 static int launch_conv_thin(const ConvParams& p, hipStream_t stream) {
@@ -1314,7 +1302,7 @@ extern "C" int sv_conv_fwd(const float* in, int64_t V_in, int64_t in_ld, int Cin
   static const bool no_first = getenv("SV_CONV_NO_FIRST") != nullptr;  // experiments only
   if (has_plan && K > 1 && K <= 27 && Cin == 3 && Cout == 32 && !no_first) return launch_conv_first_layer(p, stream);
   static const bool no_thin = getenv("SV_CONV_NO_THIN") != nullptr;  // experiments only
-  if (has_plan && K > 1 && K <= 32 && Cin == 32 && Cout == 32 && p.vec_a && !no_thin) return launch_conv_thin(p, stream);
+  if (has_plan && K > 1 && K <= 32 && Cin == 32 && Cout == 32 && p.vec_a && p.buf_ok && !no_thin) return launch_conv_thin(p, stream);
   static const bool no_narrow = getenv("SV_CONV_NO_NARROW") != nullptr;  // experiments only
   if (!has_plan && K == 1 && Cout <= 4 && p.vec_a && Cin >= 64 && !no_narrow) return launch_linear_narrow(p, stream);
   return select_and_launch(p, stream);
