@@ -15,6 +15,7 @@ timed region) and, at N = 1, `cpu_baseline` = the C oracle (oracle/sv_oracle.c, 
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -483,9 +484,13 @@ def main():
         pipe.single = False
         profiling.TIMER = None
         warm = warm_timer.summarize()
-        # dominant = most algorithmic flops (time-ranked would be fooled by the first launch after an idle gap, whose
-        # event interval absorbs the gap); on this path it is also the kernel with the most GPU time (profiles/)
-        dominant = max(warm.items(), key=lambda kv: kv[1]["flops"])[0]
+        warm_by_layer = warm_timer.summarize(by_layer=True)
+        # dominant = the (kernel instance, layer shape) with the most algorithmic flops - launches that all process the
+        # same kind of unit, so that "flops per launch / average launch duration" means something (one instance serves
+        # several layer shapes: since the dispatch thresholds favour tall tiles, the dual-body kernel runs levels 0 AND
+        # 1).  Time-ranking would be fooled by the first launch after an idle gap, whose event interval absorbs the gap.
+        dominant_layer = max(warm_by_layer.items(), key=lambda kv: kv[1]["flops"])[0]
+        dominant = dominant_layer[0]
         run_frames(model, pipe, frames, nwarm, warm_hist)
         pipe.drain()
         torch.cuda.synchronize()
@@ -542,13 +547,15 @@ def main():
 
     if rank == 0:
         ksum = timer.summarize()
-        dom = max(ksum.items(), key=lambda kv: kv[1]["ms"]) if ksum else None
+        ksum_by_layer = timer.summarize(by_layer=True)
         roofline = None
-        if dom is not None:
-            name, d = dom
+        if dominant_layer in ksum_by_layer:
+            name, d = dominant, ksum_by_layer[dominant_layer]
+            _, lK, lCin, lCout, lrows = dominant_layer
             tflops = d["flops"] / (d["ms"] * 1e-3) / 1e12
             roofline = {
-                "kernel": name, "bound": "mfma", "achieved": round(tflops, 3), "peak": PEAK_F32_MFMA_TFLOPS,
+                "kernel": name, "layer": f"kernel volume {lK}, {lCin} -> {lCout} channels, ~2^{lrows} output rows",
+                "bound": "mfma", "achieved": round(tflops, 3), "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                 "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                 "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
@@ -562,15 +569,27 @@ def main():
                 tfile = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
                 tj = json.load(open(tfile))
                 tr = tj["kernels"].get(name)
+                groups = tj.get("kernels_by_grid", {}).get(name)
+                if groups:  # the launches of this layer shape: the group whose grid is closest to this layer's
+                    rows = warm_by_layer[dominant_layer]["rows"] / warm_by_layer[dominant_layer]["launches"]
+                    want_grid = rows / 64.0 * 2.3  # 64-row tiles x 2 column halves + 15 % of the tiles at half height
+                    tr = min(groups, key=lambda g: abs(math.log(g["grid_workgroups"] / want_grid)))
                 if tr:
                     roofline["traffic"] = tr["traffic_GB_per_launch"]
                     roofline["traffic_unit"] = "GB per launch (PMC, calibrated)"
                     roofline["traffic_source"] = {"file": "profiles/" + os.path.basename(tfile),
                                                   "collected_at_commit": tj.get("commit", "unknown")}
-                    roofline["algorithmic_GB_per_launch"] = round(warm[name]["bytes"] / warm[name]["launches"] / 1e9, 4)
+                    roofline["algorithmic_GB_per_launch"] = round(
+                        warm_by_layer[dominant_layer]["bytes"] / warm_by_layer[dominant_layer]["launches"] / 1e9, 4)
             except (OSError, KeyError, ValueError):
                 pass
-            iso = warm[name]
+            # every launch of that kernel instance in the timed region, whatever the layer (levels 0 and 1, K = 27 and 8,
+            # Cin 384 and 416): the aggregate the roofline object carried before it was split by layer shape
+            allk = ksum[name]
+            all_tf = allk["flops"] / (allk["ms"] * 1e-3) / 1e12
+            roofline["all_launches_of_kernel"] = {"achieved": round(all_tf, 3), "frac": round(all_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                                                  "launches": allk["launches"]}
+            iso = warm_by_layer[dominant_layer]
             iso_tf = iso["flops"] / (iso["ms"] * 1e-3) / 1e12
             # the same instance with nothing else on the GPU (warm-up pass on one compute stream): with several compute
             # streams the timed-region duration of a launch includes the time it shares the CUs with the other frame

@@ -85,6 +85,9 @@ __device__ __forceinline__ auto buffer_load_floats(__amdgpu_buffer_rsrc_t rsrc, 
     return __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0));
   }
 }
+#ifndef SV_CONV_WANT_SCALE_DEFAULT
+#define SV_CONV_WANT_SCALE_DEFAULT 0.3  // see select_and_launch
+#endif
 #ifndef SV_CONV_TAIL_DEFAULT
 #define SV_CONV_TAIL_DEFAULT 0.15  // share of the plan tiles (the cheapest) that chip-filling launches run as half-height tiles
 #endif  // plans (perm / nbr_s / submask) are laid out in 128-row tiles
@@ -1244,7 +1247,15 @@ static int select_and_launch(const ConvParams& p, hipStream_t stream) {
     Candidate c = {0, 0, 0, 0, 0};
     if (sscanf(f, "%d,%d,%d,%d", &c.tm, &c.wn, &c.nt, &c.cpo) >= 3) return launch_candidate(c, p, stream);
   }
-  static const double want_scale = getenv("SV_CONV_WANT_SCALE") ? atof(getenv("SV_CONV_WANT_SCALE")) : 1.0;
+  // The `want` figures of the lists were measured one launch at a time (profiles/*_conv_instance_sweep.txt).  Inside the
+  // two-stream frame pipeline the taller tile wins earlier: its weight traffic per flop is lower (level 1, 384 -> 384:
+  // 64-row tiles read W once per 64 rows, 16-row tiles once per 16 - alone on the GPU both run at ~107 TFLOP/s, with
+  // perfect weight locality the 16-row tile would gain 7 %), and the launch tail that costs the short grid alone is
+  // filled by the neighbour frame's kernels.  Scaling every threshold by 0.3 moves level 1 (830 workgroups of 64 x 192)
+  // onto the dual-body launch and leaves levels 2-4 where they were: frames/s 60.9 -> 62.0 (0.15: 62.1, 0.08: 61.1,
+  // 0.03: 60.7; three alternating runs each).
+  static const double want_scale =
+      getenv("SV_CONV_WANT_SCALE") ? atof(getenv("SV_CONV_WANT_SCALE")) : SV_CONV_WANT_SCALE_DEFAULT;
   // chip-filling 384-wide layers: 64-row tiles, and 32-row tiles for the cheapest plan tiles at the end of the grid
   static const double tail_fraction = getenv("SV_CONV_TAIL") ? atof(getenv("SV_CONV_TAIL")) : SV_CONV_TAIL_DEFAULT;
   for (int i = 0; i < n; ++i)

@@ -4,6 +4,8 @@ bench.py installs a KernelTimer; nn.conv_forward reports each sv_conv_fwd launch
 roofline needs (kernel offsets K, Cin, Cout, output rows, and the device-side pair count of the plan).  Nothing is
 read back inside the timed region: events and pair counts are resolved after the final synchronize.
 """
+import math
+
 import torch
 
 TIMER = None  # set by bench.py
@@ -22,6 +24,7 @@ _CANDIDATES = {
 
 
 CONV_TAIL_FRACTION = 0.15  # SV_CONV_TAIL_DEFAULT of csrc/sv_conv.hip
+CONV_WANT_SCALE = 0.3  # SV_CONV_WANT_SCALE_DEFAULT of csrc/sv_conv.hip (thresholds re-weighted for the two-stream pipeline)
 
 
 _FUSED = {  # (Cin, Cout) -> candidates of the fused-offset form (thin layers, K > 1)
@@ -65,7 +68,7 @@ def conv_kernel_config(Cout, Vpad, Cin=None, K=1):
     suffix = f", fused {Cin}>" if fused is not None else ">"
     for tm, wn, nt, want in cands:
         tn = wn * nt * 16
-        if (Vpad // tm) * ((Cout + tn - 1) // tn) >= want:
+        if (Vpad // tm) * ((Cout + tn - 1) // tn) >= want * CONV_WANT_SCALE:
             if ((tm, wn, nt) == (64, 4, 3) and fused is None and K > 1 and Cin is not None and Cin % 4 == 0
                     and Cout % tn == 0 and int((Vpad // 128) * CONV_TAIL_FRACTION) >= 1):
                 return "conv_fwd_dual_kernel<64, 32, 4, 3>"  # chip-filling layer: half-height tiles at the end of the grid
@@ -113,16 +116,27 @@ class KernelTimer:
     def clear(self):
         self.records = []
 
-    def summarize(self):
+    @staticmethod
+    def layer_key(kernel, K, Cin, Cout, V_out):
+        """(kernel instance, layer shape): launches that process the same kind of unit - the same kernel volume and
+        channel counts on the same pyramid level (rows to the nearest power of two: the frames of a pool differ by
+        < 1 % in voxel count, pyramid levels by 3-4x)."""
+        return (kernel, K, Cin, Cout, int(round(math.log2(max(V_out, 1)))))
+
+    def summarize(self, by_layer=False):
         """After torch.cuda.synchronize(): per-kernel {launches, ms, flops, gather_bytes} (SURVEY.md §8d formulas:
-        flops = 2 P Cin Cout; gather-bytes = P (4 Cin + 8) + 4 N_out Cout + 4 K Cin Cout)."""
+        flops = 2 P Cin Cout; gather-bytes = P (4 Cin + 8) + 4 N_out Cout + 4 K Cin Cout).  by_layer: keyed by
+        layer_key() instead of the kernel name alone (an instance that serves several layer shapes has no one
+        "flops per launch")."""
         out = {}
         for kernel, K, Cin, Cout, V_out, pairs_dev, s, e, first in self.records:
             if first:
                 continue
             P = int(pairs_dev.item()) if pairs_dev is not None else V_out
             ms = s.elapsed_time(e)
-            d = out.setdefault(kernel, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            key = self.layer_key(kernel, K, Cin, Cout, V_out) if by_layer else kernel
+            d = out.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "rows": 0.0})
+            d["rows"] += V_out
             d["launches"] += 1
             d["ms"] += ms
             d["flops"] += 2.0 * P * Cin * Cout

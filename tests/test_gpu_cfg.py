@@ -113,7 +113,7 @@ def test_cfg2_full_network_bit_exact(gpu, oracle, cfg2):
         out = model(x)
         label, conf = out.slice_argmax(field)
     used = set(rec.names)
-    for inst in ("conv_fwd_dual_kernel<64, 32, 4, 3>", "conv_fwd_kernel<64, 4, 3>", "conv_fwd_kernel<64, 4, 2>",
+    for inst in ("conv_fwd_dual_kernel<64, 32, 4, 3>", "conv_fwd_kernel<64, 4, 3>",
                  "conv_fwd_kernel<16, 4, 3>", "conv_fwd_kernel<128, 4, 2>",
                  "conv_first_layer_kernel<3, 32>", "linear_narrow_kernel<3>"):
         assert inst in used, (inst, sorted(used))

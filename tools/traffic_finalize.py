@@ -50,6 +50,32 @@ for name, b in raw["bench"].items():
 for k, (n, r, w) in sorted(acc.items()):
     out["kernels"][k] = {"launches": n, "read_GB_per_launch": round(r / n / 1e9, 4),
                          "write_GB_per_launch": round(w / n / 1e9, 4), "traffic_GB_per_launch": round((r + w) / n / 1e9, 4)}
+# the same per (kernel instance, grid size): one instance serves several layer shapes (the dual-body kernel runs pyramid
+# levels 0 and 1); grids within 5 % of each other (the frames of the pool differ by < 1 % in voxel count) are one group
+out["kernels_by_grid"] = {}
+for name, grids in raw.get("bench_by_grid", {}).items():
+    k = fold(name)
+    groups = out["kernels_by_grid"].setdefault(k, [])
+    for wgs, b in sorted(grids.items(), key=lambda kv: int(kv[0])):
+        if "FETCH_SIZE" not in b or "WRITE_SIZE" not in b:
+            continue
+        n = b["FETCH_SIZE"]["launches"]
+        r = b["FETCH_SIZE"]["per_launch"] * n * 1024 * ff
+        w = b["WRITE_SIZE"]["per_launch"] * n * 1024 * wf
+        for g in groups:
+            if abs(int(wgs) - g["_wgs"] / g["launches"]) <= 0.05 * g["_wgs"] / g["launches"]:
+                g["launches"] += n; g["_wgs"] += int(wgs) * n; g["_r"] += r; g["_w"] += w
+                break
+        else:
+            groups.append({"launches": n, "_wgs": int(wgs) * n, "_r": r, "_w": w})
+for k, groups in out["kernels_by_grid"].items():
+    for g in groups:
+        n = g["launches"]
+        g["grid_workgroups"] = round(g.pop("_wgs") / n)
+        r, w = g.pop("_r"), g.pop("_w")
+        g["read_GB_per_launch"] = round(r / n / 1e9, 4)
+        g["write_GB_per_launch"] = round(w / n / 1e9, 4)
+        g["traffic_GB_per_launch"] = round((r + w) / n / 1e9, 4)
 tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
 out["commit"] = sys.argv[3] if len(sys.argv) > 3 else "unknown"
 out["source"] = out["source"].replace("bench.py --steps", "bench.py --no-cpu-baseline --no-extras --steps")
