@@ -61,8 +61,8 @@ _spawn_ranks_if_needed()
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-# HIP multiplexes streams onto a few hardware queues (4 by default); the pipeline uses a prep stream plus two compute
-# streams besides torch's default one, and two compute streams sharing a queue would serialise.  Must be set before HIP
+# HIP multiplexes streams onto a few hardware queues (4 by default); the pipeline uses a prep stream plus three compute
+# streams besides torch's default one, and compute streams sharing a queue would serialise.  Must be set before HIP
 # initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # idle OpenMP workers sleep instead of spinning: the oracle's team (cpu_baseline / accuracy legs) and torch's CPU pool
@@ -119,7 +119,7 @@ def make_frame(seed, device, n=POINTS, L=ROOM, batch=1):
 
 
 def run_frames(model, pipe, frames, steps, hist=None):
-    """Process `steps` frames through the two-stream pipeline (mrcc_amd/app/pipeline.py): while the U-Net of frame i
+    """Process `steps` frames through the multi-stream pipeline (mrcc_amd/app/pipeline.py): while the U-Net of frame i
     runs on the compute stream, the host builds frame i+1's coordinate maps / plans on the prep stream.  Every frame
     is voxelised and mapped from scratch; all work of all `steps` frames is enqueued (and, by the caller's
     synchronize, finished) inside the caller's timed region."""
@@ -416,7 +416,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pool", type=int, default=4, help="distinct frames resident per rank")
     ap.add_argument("--no-kernel-timer", action="store_true", help="diagnostic: drop the per-launch HIP events")
-    ap.add_argument("--streams", type=int, default=2, help="compute streams alternating between frames (1 = single)")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="compute streams alternating between frames (1 = single; 3: 63.1-64.3 frames/s, 2: 61.6-62.0, "
+                         "4 / 5: 63.4 / 64.0 - tools/ab_args.sh)")
     ap.add_argument("--frames-per-step", type=int, default=1,
                     help="frames fused into one sparse tensor per step (batch column); 1 = the headline workload")
     ap.add_argument("--batched-frames", type=int, default=4,
