@@ -61,7 +61,7 @@ _spawn_ranks_if_needed()
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-# HIP multiplexes streams onto a few hardware queues (4 by default); the pipeline uses a prep stream plus three compute
+# HIP multiplexes streams onto a few hardware queues (4 by default); the pipeline uses a prep stream plus two or three compute
 # streams besides torch's default one, and compute streams sharing a queue would serialise.  Must be set before HIP
 # initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
@@ -416,9 +416,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pool", type=int, default=4, help="distinct frames resident per rank")
     ap.add_argument("--no-kernel-timer", action="store_true", help="diagnostic: drop the per-launch HIP events")
-    ap.add_argument("--streams", type=int, default=3,
-                    help="compute streams alternating between frames (1 = single; 3: 63.1-64.3 frames/s, 2: 61.6-62.0, "
-                         "4 / 5: 63.4 / 64.0 - tools/ab_args.sh)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="compute streams alternating between frames (1 = single: 55 frames/s; 2: 61.6-62.0; 3: 63.1-64.3, "
+                         "4 / 5: 63.4 / 64.0 - tools/ab_args.sh.  Every additional frame in flight stretches each launch's "
+                         "duration - the dominant layer's launches run at 0.73 of the matrix peak alone, 0.60 with two "
+                         "streams, 0.44 with three - so the default stays at two: the roofline object of the line is "
+                         "the timed region's)")
     ap.add_argument("--frames-per-step", type=int, default=1,
                     help="frames fused into one sparse tensor per step (batch column); 1 = the headline workload")
     ap.add_argument("--batched-frames", type=int, default=4,
