@@ -59,6 +59,8 @@ extern "C" {
 typedef void* sv_stream_t;
 
 const char* sv_last_error(void);
+/* 2: sv_conv_fwd takes V_in (rows of `in`); sv_single_linkage_roots / sv_select_equal added */
+#define SV_ABI_VERSION 2
 int sv_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------

@@ -10,6 +10,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+ABI_VERSION = 2  # SV_ABI_VERSION of include/sv_hip.h
 LIB_PATH = os.environ.get("SVHIP_LIB") or os.path.join(_HERE, "libsvhip.so")  # SVHIP_LIB: kernel A/B experiments
 
 SV_ACT_NONE, SV_ACT_RELU, SV_ACT_LEAKY_RELU = 0, 1, 2
@@ -82,6 +83,10 @@ def load():
             "(or `make -C markerless-robot-camera-calibration_amd/csrc`). There is no CPU fallback."
         )
     lib = ctypes.CDLL(LIB_PATH)
+    lib.sv_abi_version.restype = c_int
+    if lib.sv_abi_version() != ABI_VERSION:  # a stale build would misread the arguments of a call whose signature moved
+        raise SvHipError(f"{LIB_PATH} has C-ABI version {lib.sv_abi_version()}, this package binds version {ABI_VERSION}: "
+                         "rebuild it (`python -c 'import __graft_entry__ as g; g.build()'`)")
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res

@@ -382,7 +382,7 @@ using namespace sv;
 extern "C" {
 
 const char* sv_last_error(void) { return sv::g_err; }
-int sv_abi_version(void) { return 1; }
+int sv_abi_version(void) { return SV_ABI_VERSION; }
 
 static size_t sort_pairs_u64_temp_bytes(int64_t n) { return radix_sort_temp_bytes(n, sizeof(uint64_t)); }
 static size_t sort_pairs_u32_temp_bytes(int64_t n) { return radix_sort_temp_bytes(n, sizeof(uint32_t)); }
