@@ -61,7 +61,7 @@ _spawn_ranks_if_needed()
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-# HIP multiplexes streams onto a few hardware queues (4 by default); the pipeline uses a prep stream plus two or three compute
+# HIP multiplexes streams onto a few hardware queues (4 by default); the pipeline uses a prep stream plus up to five compute
 # streams besides torch's default one, and compute streams sharing a queue would serialise.  Must be set before HIP
 # initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
@@ -416,12 +416,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pool", type=int, default=4, help="distinct frames resident per rank")
     ap.add_argument("--no-kernel-timer", action="store_true", help="diagnostic: drop the per-launch HIP events")
-    ap.add_argument("--streams", type=int, default=2,
-                    help="compute streams alternating between frames (1 = single: 55 frames/s; 2: 61.6-62.0; 3: 63.1-64.3, "
-                         "4 / 5: 63.4 / 64.0 - tools/ab_args.sh.  Every additional frame in flight stretches each launch's "
-                         "duration - the dominant layer's launches run at 0.73 of the matrix peak alone, 0.60 with two "
-                         "streams, 0.44 with three - so the default stays at two: the roofline object of the line is "
-                         "the timed region's)")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="compute streams alternating between frames, level-0 stages taking turns (app/pipeline.py).  "
+                         "frames/s and the dominant layer's per-launch fraction of the matrix peak in the timed region "
+                         "(tools/ab_env_roof.sh): 1 stream 55 / 0.73, 2: 61.7 / 0.61, 3: 64.2 / 0.50, 4: 63.4 / 0.58, "
+                         "5: 63.8 / 0.55 - every frame in flight stretches the launches it shares the chip with")
     ap.add_argument("--frames-per-step", type=int, default=1,
                     help="frames fused into one sparse tensor per step (batch column); 1 = the headline workload")
     ap.add_argument("--batched-frames", type=int, default=4,

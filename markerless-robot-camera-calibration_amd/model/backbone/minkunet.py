@@ -78,11 +78,18 @@ class MinkUNetBase(ResNetBase):
     def forward_except_final(self, x):
         out, skips = self.encode(x)
         n = self.N_LEVELS
+        from ... import profiling
+
         for j in range(n, 2 * n):
             conv, bn, block = self._up_names(j)
+            hook = profiling.PHASE_HOOK if j == 2 * n - 1 else None
+            if hook is not None:
+                hook("level0_begin")
             # transposed conv + BN + ReLU written straight into the left columns of ME.cat(out, skip)
             out = getattr(self, conv).forward_fused(out, bn=getattr(self, bn), act=SV_ACT_RELU, cat_with=skips.pop())
             out = getattr(self, block)(out)
+            if hook is not None:
+                hook("level0_end")
         return out
 
     def forward(self, x, final_act=SV_ACT_NONE, final_slope=0.01):

@@ -9,6 +9,9 @@ import math
 import torch
 
 TIMER = None  # set by bench.py
+# Optional callable(tag) the backbone calls at "level0_begin" / "level0_end" (its stride-1 decoder stage, the chip-filling
+# 63 % of a frame): the frame pipeline uses it to keep the level-0 stages of consecutive frames from overlapping.
+PHASE_HOOK = None
 
 
 _CANDIDATES = {

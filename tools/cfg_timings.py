@@ -40,7 +40,7 @@ with torch.no_grad():
         pts, rgb, _ = mrcc_amd.synth.gen_room(500_000, 2.4, s)
         c4 = np.concatenate([np.zeros((len(pts), 1), np.float32), pts * np.float32(100)], axis=1)
         frames.append((torch.from_numpy(c4).to(dev), torch.from_numpy(rgb).to(dev)))
-    pipe = FramePipeline(dev, levels=4, compute_streams=2)
+    pipe = FramePipeline(dev, levels=4, compute_streams=4)
     V = [0]
 
     def unet(x, field):
