@@ -159,7 +159,11 @@ def test_inference_engine_pipeline(gpu, oracle):
         Config.reset()
 
 
-def test_frame_pipeline_matches_direct_path(gpu):
+@pytest.mark.parametrize("streams", [1, 2, 4])
+def test_frame_pipeline_matches_direct_path(gpu, streams):
+    """prep stream + `streams` compute streams, consecutive frames on consecutive streams with their level-0 stages
+    handed over by device-side events (FramePipeline._phase_hook): every frame's logits are BIT-identical to running it
+    alone on the default stream, in whatever way the frames overlap."""
     import mrcc_amd
     from mrcc_amd import MinkowskiEngine as ME
     from mrcc_amd.app.pipeline import FramePipeline
@@ -168,26 +172,33 @@ def test_frame_pipeline_matches_direct_path(gpu):
     torch.manual_seed(1)
     net = MinkUNet14A(3, 4).to(gpu).eval()
     frames = []
-    for s in range(3):
-        pts, rgb, _ = mrcc_amd.synth.gen_room(4000, 0.5, 40 + s)
+    n = 9
+    for s in range(n):
+        pts, rgb, _ = mrcc_amd.synth.gen_room(4000 + 700 * (s % 4), 0.5, 40 + s)
         c = torch.from_numpy(np.concatenate([np.zeros((len(pts), 1), np.float32), pts * 50], axis=1)).to(gpu)
         frames.append((c, torch.from_numpy(rgb).to(gpu)))
-    pipe = FramePipeline(gpu, levels=4)
+    pipe = FramePipeline(gpu, levels=4, compute_streams=streams)
+    assert pipe.stagger_level0
     with torch.no_grad():
         direct = []
         for c, f in frames:
             fld = ME.TensorField(f, c, device=gpu)
-            direct.append(net(fld.sparse()).slice_argmax(fld)[0].clone())
+            out = net(fld.sparse())
+            direct.append((out.F.clone(), out.slice_argmax(fld)[0].clone()))
         nxt = pipe.prepare(*frames[0])
         got = []
-        for i in range(3):
+        for i in range(n):
             cur = nxt
-            got.append(pipe.run(cur, lambda x, fld: net(x).slice_argmax(fld)[0]))
-            if i + 1 < 3:
+
+            def fn(x, fld):
+                out = net(x)
+                return out.F, out.slice_argmax(fld)[0]
+            got.append(pipe.run(cur, fn))
+            if i + 1 < n:
                 nxt = pipe.prepare(*frames[i + 1])
         pipe.drain()
-    for a, b in zip(direct, got):
-        assert torch.equal(a, b)
+    for (fa, la), (fb, lb) in zip(direct, got):
+        assert torch.equal(fa, fb) and torch.equal(la, lb)
 
 
 def test_evaluation_harness_end_to_end(gpu):
