@@ -1212,8 +1212,11 @@ static int select_and_launch(const ConvParams& p, hipStream_t stream) {
   // chip-filling size the 16-row tile in its FULL form (Cin a multiple of its 128-channel step: 384, 512) wins at every
   // level (level 1: 96.4 TFLOP/s against 90.1 for 64x128, level 3: 41 against 34 for 16x128); with a partial last chunk
   // (Cin 416 / 448, the first conv after a concatenation) it only wins once 64x128 tiles no longer fill the chip
-  static const Candidate wide3_128[] = {{64, 4, 3, 2500}, {64, 4, 2, 1200}, {16, 4, 3, 0}};
-  static const Candidate wide3_128_full[] = {{64, 4, 3, 2500}, {16, 4, 3, 0}};
+  // ({32,4,3} between them: inside the frame pipeline level 2 - 432 workgroups of 32 x 192 - is 0.8 % of a frame faster on
+  // 32-row tiles although they are 25 % slower than the 16-row tiles alone: half the weight traffic beside the chip-filling
+  // launches of the other frames; 64.3 against 63.8 frames/s, three alternating runs, tools/ab_env.sh)
+  static const Candidate wide3_128[] = {{64, 4, 3, 2500}, {64, 4, 2, 1200}, {32, 4, 3, 1200}, {16, 4, 3, 0}};
+  static const Candidate wide3_128_full[] = {{64, 4, 3, 2500}, {32, 4, 3, 1200}, {16, 4, 3, 0}};
   static const Candidate wide2[] = {{128, 4, 2, 1300}, {64, 4, 2, 1500}, {32, 4, 2, 1500}, {32, 2, 2, 0}};
   static const Candidate wide2_64[] = {{128, 4, 2, 1300}, {64, 4, 2, 1500}, {32, 4, 2, 1500}, {16, 4, 1, 0}};  // % 64
   static const Candidate c64[] = {{64, 4, 1, 1500}, {32, 4, 1, 1500}, {16, 4, 1, 0}};
@@ -1224,8 +1227,8 @@ static int select_and_launch(const ConvParams& p, hipStream_t stream) {
   const int Cout = p.Cout;
   if (Cout > 128 && (Cout % 192 == 0 || Cout % 96 == 0 || Cout > 2048)) {
     if (Cout % 128 != 0) { list = wide3; n = 3; }
-    else if (p.Cin % 128 == 0 && p.vec_a) { list = wide3_128_full; n = 2; }
-    else { list = wide3_128; n = 3; }
+    else if (p.Cin % 128 == 0 && p.vec_a) { list = wide3_128_full; n = 3; }
+    else { list = wide3_128; n = 4; }
   }
   else if (Cout > 64) { list = Cout % 64 == 0 ? wide2_64 : wide2; n = 4; }
   else if (Cout > 32) { list = c64; n = 3; }
@@ -1242,6 +1245,21 @@ static int select_and_launch(const ConvParams& p, hipStream_t stream) {
     else if (p.Cin == 32 && p.vec_a && Cout == 32) { list = f32_32; n = 2; }
     else if (p.Cin == 32 && p.vec_a && Cout == 64) { list = f32_64; n = 2; }
     else if (p.Cin == 64 && p.vec_a && (Cout == 64 || Cout == 128)) { list = f64_64; n = 2; }
+  }
+  if (const char* f = getenv("SV_CONV_FORCE_RANGE")) {  // "vmin:vmax:cout:tm,wn,nt": one level's layers only (experiments)
+    long long vmin = 0, vmax = 0;
+    int cout = 0;
+    Candidate c = {0, 0, 0, 0, 0};
+    if (sscanf(f, "%lld:%lld:%d:%d,%d,%d", &vmin, &vmax, &cout, &c.tm, &c.wn, &c.nt) == 6 && p.Vpad >= vmin && p.Vpad <= vmax &&
+        p.Cout == cout && p.K > 1)
+      return launch_candidate(c, p, stream);
+  }
+  if (const char* f = getenv("SV_CONV_FORCE_DENSE")) {  // "vmin:cout:tm,wn,nt": dense (K = 1) layers of one width (experiments)
+    long long vmin = 0;
+    int cout = 0;
+    Candidate c = {0, 0, 0, 0, 0};
+    if (sscanf(f, "%lld:%d:%d,%d,%d", &vmin, &cout, &c.tm, &c.wn, &c.nt) == 5 && p.Vpad >= vmin && p.Cout == cout && p.K == 1)
+      return launch_candidate(c, p, stream);
   }
   if (const char* f = getenv("SV_CONV_FORCE")) {  // "tm,wn,nt[,cpo]": experiments only
     Candidate c = {0, 0, 0, 0, 0};

@@ -16,8 +16,8 @@ PHASE_HOOK = None
 
 _CANDIDATES = {
     "wide3": [(64, 4, 3, 2500), (32, 4, 3, 1500), (32, 2, 3, 0)],
-    "wide3_128": [(64, 4, 3, 2500), (64, 4, 2, 1200), (16, 4, 3, 0)],
-    "wide3_128_full": [(64, 4, 3, 2500), (16, 4, 3, 0)],  # Cin a multiple of the 16-row tile's 128-channel step
+    "wide3_128": [(64, 4, 3, 2500), (64, 4, 2, 1200), (32, 4, 3, 1200), (16, 4, 3, 0)],
+    "wide3_128_full": [(64, 4, 3, 2500), (32, 4, 3, 1200), (16, 4, 3, 0)],  # Cin a multiple of the 16-row tile's 128-channel step
     "wide2": [(128, 4, 2, 1300), (64, 4, 2, 1500), (32, 4, 2, 1500), (32, 2, 2, 0)],
     "wide2_64": [(128, 4, 2, 1300), (64, 4, 2, 1500), (32, 4, 2, 1500), (16, 4, 1, 0)],
     "c64": [(64, 4, 1, 1500), (32, 4, 1, 1500), (16, 4, 1, 0)],

@@ -110,8 +110,8 @@ def test_strided_input_and_affine(gpu, oracle):
 @pytest.mark.parametrize("level,cin", [(0, 32), (1, 64), (1, 128), (2, 96), (3, 128), (3, 96)])
 def test_conv_every_tile_shape_of_the_pyramid_bit_exact(gpu, oracle, level, cin):
     """The Cfg-2 pyramid (88k / 26k / 7k / 2k voxels) with 384 output channels walks the dispatch table of the wide
-    layers: 64x192 (+ 32x192 tail tiles in one launch) on levels 0-1 and 16x192 (register-ring; FULL form when Cin is a multiple
-    of 128) tiles below; 64x128 is covered by the forced-instance cases of test_gpu_cfg.py.  Narrow inputs keep
+    layers: 64x192 (+ 32x192 tail tiles in one launch) on levels 0-1, 32x192 on level 2 and 16x192 (register-ring; FULL form
+    when Cin is a multiple of 128) tiles on level 3; 64x128 is covered by the forced-instance cases of test_gpu_cfg.py.  Narrow inputs keep
     the oracle fast."""
     import mrcc_amd
     from mrcc_amd import MinkowskiEngine as ME
@@ -126,7 +126,7 @@ def test_conv_every_tile_shape_of_the_pyramid_bit_exact(gpu, oracle, level, cin)
     plan = cm.plan_k3(ts)
     V = cm.stride_map(ts).V
     expect = {0: "conv_fwd_dual_kernel<64, 32, 4, 3>", 1: "conv_fwd_dual_kernel<64, 32, 4, 3>",
-              2: "conv_fwd_kernel<16, 4, 3>", 3: "conv_fwd_kernel<16, 4, 3>"}[level]
+              2: "conv_fwd_kernel<32, 4, 3>", 3: "conv_fwd_kernel<16, 4, 3>"}[level]
     assert profiling.conv_kernel_config(384, plan.Vpad, cin, 27) == expect
     frame = oracle.Frame(oracle.voxelize(coords4)["coords"])
     for l in range(level):

@@ -109,12 +109,13 @@ def test_kernel_dispatch_mirror():
     assert c(384, 26624) == "conv_fwd_kernel<64, 4, 3>"        # Cin unknown: plain launch of the 64-row tile
     assert c(384, 26624, 416, 27) == "conv_fwd_dual_kernel<64, 32, 4, 3>"
     assert c(384, 26624, 384, 27) == "conv_fwd_dual_kernel<64, 32, 4, 3>"
-    assert c(384, 6912, 384, 27) == "conv_fwd_kernel<16, 4, 3>"  # level 2: FULL form of the 16-row tile
-    assert c(384, 6912, 448, 27) == "conv_fwd_kernel<16, 4, 3>"
+    assert c(384, 6912, 384, 27) == "conv_fwd_kernel<32, 4, 3>"  # level 2: 32-row tiles (chosen inside the pipeline)
+    assert c(384, 6912, 448, 27) == "conv_fwd_kernel<32, 4, 3>"
+    assert c(384, 1792, 384, 27) == "conv_fwd_kernel<16, 4, 3>"  # level 3: FULL form of the 16-row tile
     assert c(384, 88192, 384, 27) == "conv_fwd_dual_kernel<64, 32, 4, 3>"  # chip-filling: 64-row + 32-row tail tiles
     assert c(384, 88192, 416, 27) == "conv_fwd_dual_kernel<64, 32, 4, 3>"
     assert c(384, 88192, 416, 1) == "conv_fwd_kernel<64, 4, 3>"   # dense rows (no plan): plain launch
-    assert c(384, 6912) == "conv_fwd_kernel<16, 4, 3>"
+    assert c(384, 6912) == "conv_fwd_kernel<32, 4, 3>"
     assert c(192, 26624) == "conv_fwd_kernel<32, 4, 3>"
     assert c(384, 1792) == "conv_fwd_kernel<16, 4, 3>"
     assert c(384, 1792, 512, 27) == "conv_fwd_kernel<16, 4, 3>"
