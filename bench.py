@@ -558,7 +558,7 @@ def main():
             _, lK, lCin, lCout, lrows = dominant_layer
             tflops = d["flops"] / (d["ms"] * 1e-3) / 1e12
             roofline = {
-                "kernel": name, "layer": f"kernel volume {lK}, {lCin} -> {lCout} channels, ~2^{lrows} output rows",
+                "kernel": name, "layer": f"kernel volume {lK}, {lCin} -> {lCout} channels, output map {lrows} (s<tensor stride>)",
                 "bound": "mfma", "achieved": round(tflops, 3), "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                 "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),

@@ -59,8 +59,9 @@ extern "C" {
 typedef void* sv_stream_t;
 
 const char* sv_last_error(void);
-/* 2: sv_conv_fwd takes V_in (rows of `in`); sv_single_linkage_roots / sv_select_equal added */
-#define SV_ABI_VERSION 2
+/* 2: sv_conv_fwd takes V_in (rows of `in`); sv_single_linkage_roots / sv_select_equal added
+ * 3: sv_plan_build takes nbr_base (plans of a batch range of a kernel map); sv_key_point_predictions added */
+#define SV_ABI_VERSION 3
 int sv_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -122,9 +123,14 @@ int sv_kernel_map_up(const uint64_t* keys_fine, const int32_t* parent, int64_t V
  * submask: uint32[Vpad/128][K] bit s set = sub-tile s (rows 16s..16s+15 of the tile) has a neighbour at offset k
  * tile_order: int32[Vpad/128] plan tiles sorted by work (number of active (offset, sub-tile) slots) descending: the
  *          conv kernel dispatches its workgroups in this order (longest first) so the launch has a short tail
- * Vpad = round_up(V, 128). */
+ * Vpad = round_up(V, 128).
+ * Plans of a ROW RANGE of a kernel map (batched tensors whose feature tables exceed the 2 GB extent of the buffer-addressed
+ * conv instances: the frames of a batch never share neighbours, data/alivev2.py:358-383): pass nbr + o0 / mask + o0 / V = o1 - o0
+ * for output rows [o0, o1) and nbr_base = first input row of the range; every stored index is then relative to that row, and
+ * sv_conv_fwd runs on `in + nbr_base * in_ld`, `out + o0 * out_ld`.  nbr_base = 0 for a whole map.
+ * `perm` (and every plan array) must be 16-byte aligned: the conv epilogue reads it four entries at a time. */
 size_t sv_plan_workspace_bytes(int64_t V);
-int sv_plan_build(const int32_t* nbr, int64_t ld, const uint32_t* mask, int K, int64_t V, void* workspace,
+int sv_plan_build(const int32_t* nbr, int64_t ld, const uint32_t* mask, int K, int64_t V, int64_t nbr_base, void* workspace,
                   size_t workspace_bytes, int32_t* perm, int32_t* nbr_s, uint32_t* submask, int32_t* tile_order,
                   int64_t Vpad, sv_stream_t stream);
 
@@ -141,7 +147,9 @@ int sv_plan_build(const int32_t* nbr, int64_t ld, const uint32_t* mask, int K, i
  * perm/nbr_s/submask NULL = dense rows (kernel_size 1 / Linear): nbr = identity.  tile_order may be NULL.
  * V_in = rows of `in` (every index in nbr_s is below it; = V_out for dense rows): with it the wide-layer kernels
  * address `in` through a bounds-checked buffer descriptor (32-bit offsets, absent neighbours read as zero rows);
- * inputs of 2 GB and more take the guarded form with 64-bit addresses.
+ * inputs of 2 GB and more take the guarded form with 64-bit addresses - except dense rows (no plan, K = 1), which this
+ * entry point splits into row ranges below the extent, and batched tensors, whose callers launch one batch range at a
+ * time with plans built for that range (sv_plan_build: nbr_base).
  * One entry point, several kernels behind it (all with the chain order above, so results do not depend on the
  * choice): fp32-MFMA tiles for the wide layers, their fused-offset form for 32/64-channel inputs, a thread-per-voxel
  * VALU kernel for the 3-channel first layer and a row-streaming VALU kernel for dense layers with <= 4 outputs.
@@ -151,6 +159,10 @@ int sv_conv_fwd(const float* in, int64_t V_in, int64_t in_ld, int Cin, const flo
                 const float* scale,
                 const float* shift, const float* residual, int64_t res_ld, int act, float slope, float* out,
                 int64_t out_ld, sv_stream_t stream);
+/* Kernel instance the calling thread's last sv_conv_fwd launched: "name|fast=F,ring=R,full=U" (fast = buffer-addressed
+ * form; a tensor beyond its 2 GB extent, a misaligned plan or an odd channel count takes the guarded form).  Tests and the
+ * bench's per-kernel table read it back instead of re-deriving the dispatch. */
+const char* sv_conv_last_instance(void);
 
 /* Stand-alone BN(eval)/bias + residual + activation on feature rows, same arithmetic as the conv epilogue:
  *   out[v][c] = act( fmaf(in[v][c], scale[c], shift[c]) + residual[v][c] )

@@ -10,7 +10,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 2  # SV_ABI_VERSION of include/sv_hip.h
+ABI_VERSION = 3  # SV_ABI_VERSION of include/sv_hip.h
 LIB_PATH = os.environ.get("SVHIP_LIB") or os.path.join(_HERE, "libsvhip.so")  # SVHIP_LIB: kernel A/B experiments
 
 SV_ACT_NONE, SV_ACT_RELU, SV_ACT_LEAKY_RELU = 0, 1, 2
@@ -41,12 +41,13 @@ SIGNATURES = {
     "sv_kernel_map_down": (c_int, [_P, _P, c_int64, c_int, c_int64, _P, c_int64, _P, _P]),
     "sv_kernel_map_up": (c_int, [_P, _P, c_int64, c_int, _P, c_int64, _P, _P]),
     "sv_plan_workspace_bytes": (c_size_t, [c_int64]),
-    "sv_plan_build": (c_int, [_P, c_int64, _P, c_int, c_int64, _P, c_size_t, _P, _P, _P, _P, c_int64, _P]),
+    "sv_plan_build": (c_int, [_P, c_int64, _P, c_int, c_int64, c_int64, _P, c_size_t, _P, _P, _P, _P, c_int64, _P]),
     "sv_conv_fwd": (
         c_int,
         [_P, c_int64, c_int64, c_int, _P, c_int, c_int, _P, _P, _P, _P, c_int64, c_int64, _P, _P, _P, c_int64, c_int,
          c_float, _P, c_int64, _P],
     ),
+    "sv_conv_last_instance": (c_char_p, []),
     "sv_affine_act": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, _P, c_int64, c_int, c_float, _P, c_int64, _P]),
     "sv_col_stats_workspace_bytes": (c_size_t, [c_int64]),
     "sv_col_stats": (c_int, [_P, c_int64, c_int64, c_int, _P, _P, c_size_t, _P, _P, _P, _P, _P]),
@@ -116,6 +117,13 @@ def call(name, *args):
     lib = load()
     rc = getattr(lib, name)(*args)
     _check(rc, name)
+
+
+def conv_last_instance():
+    """(kernel instance name, {"fast": 0/1, "ring": 0/1, "full": 0/1}) of this thread's last sv_conv_fwd launch."""
+    raw = load().sv_conv_last_instance().decode()
+    name, _, flags = raw.partition("|")
+    return name, {k: int(v) for k, v in (kv.split("=") for kv in flags.split(",") if kv)}
 
 
 def require_cuda(t, what="tensor"):

@@ -15,6 +15,7 @@
 // Numerics: every output element is ONE f32 fma chain over (k ascending, c ascending) — the MFMA is a k-ordered
 // fmaf chain (MI355X guide §3) — so results are bitwise reproducible and match oracle/sv_oracle.c exactly.
 // A missing neighbour contributes fma(0, w, acc) = acc.
+#include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -59,6 +60,15 @@ struct ConvParams {
 };
 
 constexpr int PLAN_TILE = SV_TILE_ROWS;
+// name of the kernel instance the last sv_conv_fwd call of this thread launched, "name|fast=F,ring=R,full=U" (the names
+// mrcc_amd/profiling.py predicts; sv_conv_last_instance(): tests and the bench's per-kernel records read it back)
+static thread_local char g_last_instance[128] = "";
+static void note_instance(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_last_instance, sizeof(g_last_instance), fmt, ap);
+  va_end(ap);
+}
 // Buffer addressing of the FAST instances.  Measured with tools/mfma_probe.py on gfx950: a `global_load` with a 64-bit
 // VGPR address costs the SIMD's matrix pipe ~45 cycles of issue per instruction (one per 12 matrix ops: 0.98 -> 0.86 of
 // the peak issue rate), and every VALU instruction in the loop (address arithmetic, selects) its own execution time;
@@ -954,6 +964,7 @@ static int launch_conv_thin(const ConvParams& p, hipStream_t stream) {
   // on the LDS-staged fused-offset tile, 49 against 84 us at 88k voxels (2.65 TB/s on algorithmic gather-bytes).  Two
   // sub-tiles per wave (shared weight registers) 27-28 / 48 us, three or six offsets in flight 26 / 51-54 us.
   hipLaunchKernelGGL((conv_thin_kernel<32, 32, 1, 4>), dim3((unsigned)(p.Vpad / 64)), dim3(256), 0, stream, p);
+  note_instance("conv_thin_kernel<32, 32>|fast=1,ring=0,full=1");
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
@@ -1036,6 +1047,7 @@ static int launch_conv_first_layer(const ConvParams& p, hipStream_t stream) {
   // against 16 us: the gathers are repeated per slice)
   dim3 grid((unsigned)((p.Vpad + 255) / 256), 1);
   hipLaunchKernelGGL((conv_first_layer_kernel<3, 32, 1>), grid, dim3(256), 0, stream, p);
+  note_instance("conv_first_layer_kernel<3, 32>|fast=0,ring=0,full=0");
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
@@ -1049,6 +1061,7 @@ static int launch_linear_narrow_rows(const ConvParams& p, hipStream_t stream) {
     case 3: hipLaunchKernelGGL((linear_narrow_kernel<3, ROWS>), grid, dim3(256), 0, stream, p); break;
     default: hipLaunchKernelGGL((linear_narrow_kernel<4, ROWS>), grid, dim3(256), 0, stream, p); break;
   }
+  note_instance("linear_narrow_kernel<%d>|fast=0,ring=0,full=0", p.Cout < 4 ? p.Cout : 4);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
@@ -1100,6 +1113,14 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
       hipLaunchKernelGGL((conv_fwd_kernel<TM_, WAVES_N, NT, false, CPO, false>), grid, dim3(256), lds, stream, q);
   }
   SV_LAUNCH_CHECK();
+  {
+    const bool f = F && fast;
+    if (CPO)
+      note_instance("conv_fwd_kernel<%d, %d, %d, fused %d>|fast=%d,ring=%d,full=%d", TM_, WAVES_N, NT, CPO, (int)f, (int)ring,
+                    (int)(f && full));
+    else
+      note_instance("conv_fwd_kernel<%d, %d, %d>|fast=%d,ring=%d,full=%d", TM_, WAVES_N, NT, (int)f, (int)ring, (int)(f && full));
+  }
   if (q.trace) {
     std::vector<unsigned long long> host((size_t)grid.x * 4);
     SV_HIP(hipStreamSynchronize(stream));
@@ -1137,6 +1158,7 @@ static int launch_conv_dual(const ConvParams& p, hipStream_t stream, double tail
   if (trace_path) SV_HIP(hipMalloc((void**)&q.trace, (size_t)grid * 4 * sizeof(unsigned long long)));
   hipLaunchKernelGGL((conv_fwd_dual_kernel<TM_, TAIL_TM, WAVES_N, NT, true>), dim3(grid), dim3(256), lds, stream, q);
   SV_LAUNCH_CHECK();
+  note_instance("conv_fwd_dual_kernel<%d, %d, %d, %d>|fast=1,ring=0,full=0", TM_, TAIL_TM, WAVES_N, NT);
   if (q.trace) {
     std::vector<unsigned long long> host((size_t)grid * 4);
     SV_HIP(hipStreamSynchronize(stream));
@@ -1291,6 +1313,8 @@ static int select_and_launch(const ConvParams& p, hipStream_t stream) {
 
 using namespace sv;
 
+extern "C" const char* sv_conv_last_instance(void) { return sv::g_last_instance; }
+
 extern "C" int sv_conv_fwd(const float* in, int64_t V_in, int64_t in_ld, int Cin, const float* W, int K, int Cout,
                            const int32_t* perm, const int32_t* nbr_s, const uint32_t* submask,
                            const int32_t* tile_order, int64_t V_out, int64_t Vpad, const float* scale, const float* shift, const float* residual, int64_t res_ld,
@@ -1318,7 +1342,28 @@ extern "C" int sv_conv_fwd(const float* in, int64_t V_in, int64_t in_ld, int Cin
   const uint64_t w_bytes = (uint64_t)K * (uint64_t)Cin * (uint64_t)Cout * 4u;
   const uint64_t out_bytes = ((uint64_t)(V_out - 1) * (uint64_t)out_ld + (uint64_t)Cout) * 4u;
   const uint64_t res_bytes = residual ? ((uint64_t)(V_out - 1) * (uint64_t)res_ld + (uint64_t)Cout) * 4u : 0u;
-  p.buf_ok = in_bytes < BUF_LIMIT && w_bytes < BUF_LIMIT && out_bytes < BUF_LIMIT && res_bytes < BUF_LIMIT;
+  // (the buffer-addressed epilogue reads `perm` four entries at a time: a plan carved from a workspace at an odd offset
+  //  takes the guarded form)
+  p.buf_ok = in_bytes < BUF_LIMIT && w_bytes < BUF_LIMIT && out_bytes < BUF_LIMIT && res_bytes < BUF_LIMIT &&
+             (((uintptr_t)perm & 15) == 0);
+  if (!p.buf_ok && !has_plan && K == 1 && w_bytes < BUF_LIMIT) {
+    // dense rows (Linear / 1x1 conv) of a tensor beyond the 2 GB extent: every row range is a layer of its own, so the
+    // launch is split into ranges that fit the buffer-addressed instances (64 Cfg-2 frames x 1024 channels = 23 GB)
+    int64_t ld_max = in_ld > out_ld ? in_ld : out_ld;
+    if (residual && res_ld > ld_max) ld_max = res_ld;
+    const int64_t rows = (int64_t)((BUF_LIMIT - 4096u) / ((uint64_t)ld_max * 4u)) / PLAN_TILE * PLAN_TILE;
+    if (rows >= PLAN_TILE && rows < V_out) {
+      for (int64_t r0 = 0; r0 < V_out; r0 += rows) {
+        const int64_t n = V_out - r0 < rows ? V_out - r0 : rows;
+        const int rc = sv_conv_fwd(in + r0 * in_ld, n, in_ld, Cin, W, K, Cout, nullptr, nullptr, nullptr, nullptr, n,
+                                   (n + PLAN_TILE - 1) / PLAN_TILE * PLAN_TILE, scale, shift,
+                                   residual ? residual + r0 * res_ld : nullptr, res_ld, act, slope, out + r0 * out_ld, out_ld,
+                                   stream_);
+        if (rc != SV_OK) return rc;
+      }
+      return SV_OK;
+    }
+  }
   p.in_bytes = p.buf_ok ? (uint32_t)in_bytes : 0u;
   p.w_bytes = p.buf_ok ? (uint32_t)w_bytes : 0u;
   p.out_bytes = p.buf_ok ? (uint32_t)out_bytes : 0u;

@@ -341,7 +341,8 @@ __global__ __launch_bounds__(256) void iota_key_kernel(const uint32_t* __restric
 // block = 128 threads = one tile of rows, blockIdx.y = offset k
 __global__ __launch_bounds__(128) void plan_gather_kernel(const int32_t* __restrict__ nbr, int64_t ld,
                                                            const int32_t* __restrict__ perm_sorted, int64_t V,
-                                                           int64_t Vpad, int K, int32_t* __restrict__ perm,
+                                                           int64_t Vpad, int K, int32_t nbr_base,
+                                                           int32_t* __restrict__ perm,
                                                            int32_t* __restrict__ nbr_s,
                                                            uint32_t* __restrict__ submask) {
   int tile = blockIdx.x, k = blockIdx.y;
@@ -349,6 +350,7 @@ __global__ __launch_bounds__(128) void plan_gather_kernel(const int32_t* __restr
   int o = (r < V) ? perm_sorted[r] : -1;
   if (k == 0) perm[r] = o;
   int n = (o >= 0) ? nbr[(int64_t)k * ld + o] : -1;
+  if (n >= 0) n -= nbr_base;  // plans of a row range (sv_plan_build: nbr_base): indices relative to the range's first input row
   nbr_s[(int64_t)k * Vpad + r] = n;
   unsigned long long b = __ballot(n >= 0);
   int wid = threadIdx.x >> 6;
@@ -542,12 +544,13 @@ size_t sv_plan_workspace_bytes(int64_t V) {
          align_up((size_t)(V / 128 + 2) * 4, 256) * 3;
 }
 
-int sv_plan_build(const int32_t* nbr, int64_t ld, const uint32_t* mask, int K, int64_t V, void* workspace,
-                  size_t workspace_bytes, int32_t* perm, int32_t* nbr_s, uint32_t* submask, int32_t* tile_order,
-                  int64_t Vpad, sv_stream_t stream_) {
+int sv_plan_build(const int32_t* nbr, int64_t ld, const uint32_t* mask, int K, int64_t V, int64_t nbr_base,
+                  void* workspace, size_t workspace_bytes, int32_t* perm, int32_t* nbr_s, uint32_t* submask,
+                  int32_t* tile_order, int64_t Vpad, sv_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SV_CHECK_ARG(K >= 1 && K <= 32, "K must be in 1..32");
   SV_CHECK_ARG(V >= 0 && ld >= V, "bad shape");
+  SV_CHECK_ARG(nbr_base >= 0 && nbr_base < (1ll << 31), "nbr_base out of range");
   SV_CHECK_ARG(Vpad % SV_TILE_ROWS == 0 && Vpad >= V, "Vpad must be a multiple of 128 >= V");
   if (V == 0) return SV_OK;
   SV_CHECK_ARG(nbr && mask && perm && nbr_s && submask && workspace, "null pointer");
@@ -577,7 +580,7 @@ int sv_plan_build(const int32_t* nbr, int64_t ld, const uint32_t* mask, int K, i
   int64_t tiles = Vpad / SV_TILE_ROWS;
   SV_HIP(hipMemsetAsync(submask, 0, (size_t)tiles * K * sizeof(uint32_t), stream));
   hipLaunchKernelGGL(plan_gather_kernel, dim3((unsigned)tiles, (unsigned)K), dim3(128), 0, stream, nbr, ld, sorted_rows,
-                     V, Vpad, K, perm, nbr_s, submask);
+                     V, Vpad, K, (int32_t)nbr_base, perm, nbr_s, submask);
   SV_LAUNCH_CHECK();
   if (tile_order) {
     hipLaunchKernelGGL(tile_cost_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, submask, K,

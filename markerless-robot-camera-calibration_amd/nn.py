@@ -41,24 +41,38 @@ def conv_forward(feats, weight3, plan, V_out, scale=None, shift=None, residual=N
         out = torch.empty((V_out, Cout), dtype=torch.float32, device=feats.device)
     if plan is None:
         Vpad = (max(V_out, 1) + _lib.SV_TILE_ROWS - 1) // _lib.SV_TILE_ROWS * _lib.SV_TILE_ROWS
-        perm = nbr_s = submask = tile_order = None
     else:
-        Vpad, perm, nbr_s, submask, tile_order = plan.Vpad, plan.perm, plan.nbr_s, plan.submask, plan.tile_order
+        Vpad = plan.Vpad
     timer = profiling.TIMER
     t0 = None
     if timer is not None:
         kname = profiling.conv_kernel_config(Cout, Vpad, Cin, K)
         if timer.want(kname):
             t0 = timer.start()
-    call("sv_conv_fwd", ptr(feats), c_int64(feats.shape[0]), c_int64(feats.stride(0)), c_int(Cin), ptr(weight3), c_int(K),
-         c_int(Cout),
-         ptr(perm), ptr(nbr_s), ptr(submask), ptr(tile_order), c_int64(V_out), c_int64(Vpad), ptr(scale), ptr(shift),
-         ptr(residual),
-         c_int64(residual.stride(0) if residual is not None else 0), c_int(act), c_float(slope), ptr(out),
-         c_int64(out.stride(0)), stream_ptr())
+    res_ld = residual.stride(0) if residual is not None else 0
+
+    log = profiling.INSTANCE_LOG
+
+    def launch(f, pl, o, r, v_out, v_pad):
+        call("sv_conv_fwd", ptr(f), c_int64(f.shape[0]), c_int64(f.stride(0)), c_int(Cin), ptr(weight3), c_int(K),
+             c_int(Cout), ptr(pl.perm if pl else None), ptr(pl.nbr_s if pl else None), ptr(pl.submask if pl else None),
+             ptr(pl.tile_order if pl else None), c_int64(v_out), c_int64(v_pad), ptr(scale), ptr(shift), ptr(r),
+             c_int64(res_ld), c_int(act), c_float(slope), ptr(o), c_int64(o.stride(0)), stream_ptr())
+        if log is not None:  # what the library really launched (sv_conv_last_instance), not a re-derivation
+            log.append((*_lib.conv_last_instance(), K, Cin, Cout, v_out))
+
+    # batched tensors beyond the 2 GB extent of the buffer-addressed instances run as batch ranges (ConvPlan.chunks)
+    parts = plan.chunks(4 * feats.stride(0), 4 * max(out.stride(0), res_ld)) if plan is not None else None
+    if parts is None:
+        launch(feats, plan, out, residual, V_out, Vpad)
+    else:
+        for sub, i0, i1, o0, o1 in parts:
+            launch(feats[i0:i1], sub, out[o0:o1], residual[o0:o1] if residual is not None else None, o1 - o0, sub.Vpad)
     if t0 is not None:
-        timer.stop(t0, kname, K, Cin, Cout, V_out,
-                   plan.pairs_device() if plan is not None else None)
+        # recorded under the instance the library reports (the prediction above only decides whether to time at all)
+        timer.stop(t0, _lib.conv_last_instance()[0], K, Cin, Cout, V_out,
+                   plan.pairs_device() if plan is not None else None,
+                   level=plan.out_stride if plan is not None else None)
     return out
 
 

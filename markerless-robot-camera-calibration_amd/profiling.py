@@ -9,6 +9,9 @@ import math
 import torch
 
 TIMER = None  # set by bench.py
+# Optional list: nn.conv_forward appends (instance name, {"fast", "ring", "full"}, K, Cin, Cout, rows) per launch, as
+# reported by the library itself (sv_conv_last_instance) - tests check which instances a configuration really ran on.
+INSTANCE_LOG = None
 # Optional callable(tag) the backbone calls at "level0_begin" / "level0_end" (its stride-1 decoder stage, the chip-filling
 # 63 % of a frame): the frame pipeline uses it to keep the level-0 stages of consecutive frames from overlapping.
 PHASE_HOOK = None
@@ -26,8 +29,12 @@ _CANDIDATES = {
 }
 
 
-CONV_TAIL_FRACTION = 0.15  # SV_CONV_TAIL_DEFAULT of csrc/sv_conv.hip
-CONV_WANT_SCALE = 0.3  # SV_CONV_WANT_SCALE_DEFAULT of csrc/sv_conv.hip (thresholds re-weighted for the two-stream pipeline)
+import os  # noqa: E402
+
+# the same experiment switches select_and_launch() reads (tools/sweep_pipeline.sh, tools/ab_env*.sh vary them); what a launch
+# really ran on is reported by the library itself: _lib.conv_last_instance()
+CONV_TAIL_FRACTION = float(os.environ.get("SV_CONV_TAIL", "0.15"))  # SV_CONV_TAIL_DEFAULT of csrc/sv_conv.hip
+CONV_WANT_SCALE = float(os.environ.get("SV_CONV_WANT_SCALE", "0.3"))  # SV_CONV_WANT_SCALE_DEFAULT of csrc/sv_conv.hip
 
 
 _FUSED = {  # (Cin, Cout) -> candidates of the fused-offset form (thin layers, K > 1)
@@ -73,7 +80,7 @@ def conv_kernel_config(Cout, Vpad, Cin=None, K=1):
         tn = wn * nt * 16
         if (Vpad // tm) * ((Cout + tn - 1) // tn) >= want * CONV_WANT_SCALE:
             if ((tm, wn, nt) == (64, 4, 3) and fused is None and K > 1 and Cin is not None and Cin % 4 == 0
-                    and Cout % tn == 0 and int((Vpad // 128) * CONV_TAIL_FRACTION) >= 1):
+                    and Cout % tn == 0 and CONV_TAIL_FRACTION > 0 and int((Vpad // 128) * CONV_TAIL_FRACTION) >= 1):
                 return "conv_fwd_dual_kernel<64, 32, 4, 3>"  # chip-filling layer: half-height tiles at the end of the grid
             return f"conv_fwd_kernel<{tm}, {wn}, {nt}{suffix}"
     tm, wn, nt, _ = cands[-1]
@@ -105,10 +112,10 @@ class KernelTimer:
         e.record()
         return e
 
-    def stop(self, start_evt, kernel, K, Cin, Cout, V_out, pairs_dev):
+    def stop(self, start_evt, kernel, K, Cin, Cout, V_out, pairs_dev, level=None):
         e = self._event()
         e.record()
-        self.records.append((kernel, K, Cin, Cout, V_out, pairs_dev, start_evt, e, self._first_of_frame))
+        self.records.append((kernel, K, Cin, Cout, V_out, pairs_dev, start_evt, e, self._first_of_frame, level))
         self._first_of_frame = False
 
     def frame_boundary(self):
@@ -120,11 +127,13 @@ class KernelTimer:
         self.records = []
 
     @staticmethod
-    def layer_key(kernel, K, Cin, Cout, V_out):
+    def layer_key(kernel, K, Cin, Cout, V_out, level=None):
         """(kernel instance, layer shape): launches that process the same kind of unit - the same kernel volume and
-        channel counts on the same pyramid level (rows to the nearest power of two: the frames of a pool differ by
-        < 1 % in voxel count, pyramid levels by 3-4x)."""
-        return (kernel, K, Cin, Cout, int(round(math.log2(max(V_out, 1)))))
+        channel counts on the same pyramid level, named by the output's tensor stride ("s1", "s2", ...) where the launch
+        has a plan; dense layers (no plan, hence no level) by their rows to the nearest power of two ("~2^17": the frames
+        of a pool differ by < 1 % in voxel count, pyramid levels by 3-4x)."""
+        where = f"s{level}" if level is not None else f"~2^{int(round(math.log2(max(V_out, 1))))}"
+        return (kernel, K, Cin, Cout, where)
 
     def summarize(self, by_layer=False):
         """After torch.cuda.synchronize(): per-kernel {launches, ms, flops, gather_bytes} (SURVEY.md §8d formulas:
@@ -132,12 +141,12 @@ class KernelTimer:
         layer_key() instead of the kernel name alone (an instance that serves several layer shapes has no one
         "flops per launch")."""
         out = {}
-        for kernel, K, Cin, Cout, V_out, pairs_dev, s, e, first in self.records:
+        for kernel, K, Cin, Cout, V_out, pairs_dev, s, e, first, level in self.records:
             if first:
                 continue
             P = int(pairs_dev.item()) if pairs_dev is not None else V_out
             ms = s.elapsed_time(e)
-            key = self.layer_key(kernel, K, Cin, Cout, V_out) if by_layer else kernel
+            key = self.layer_key(kernel, K, Cin, Cout, V_out, level) if by_layer else kernel
             d = out.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "rows": 0.0})
             d["rows"] += V_out
             d["launches"] += 1

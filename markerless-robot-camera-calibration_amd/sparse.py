@@ -63,15 +63,24 @@ class CoordinateMap:
         return self._hash
 
 
+BUF_LIMIT = 0x7fff0000 - 4096  # extent (bytes) the buffer-addressed conv instances take (csrc/sv_conv.hip BUF_LIMIT)
+
+
 class ConvPlan:
     """Mask-sorted execution plan of one kernel map (include/sv_hip.h sv_plan_build)."""
 
-    __slots__ = ("perm", "nbr_s", "submask", "tile_order", "V_out", "Vpad", "K", "pairs")
+    __slots__ = ("perm", "nbr_s", "submask", "tile_order", "V_out", "Vpad", "K", "pairs", "cm", "in_stride",
+                 "out_stride", "raw", "_chunked")
 
     def __init__(self, perm, nbr_s, submask, tile_order, V_out, Vpad, K):
         self.perm, self.nbr_s, self.submask, self.tile_order = perm, nbr_s, submask, tile_order
         self.V_out, self.Vpad, self.K = V_out, Vpad, K
         self.pairs = None  # number of (in,out) pairs, filled lazily for roofline accounting
+        # set by the coordinate manager for plans of a whole kernel map: what chunks() needs to re-plan a batch range
+        self.cm = None
+        self.in_stride = self.out_stride = None
+        self.raw = None  # (nbr int32[K, ld], ld, mask) - the unsorted kernel map
+        self._chunked = {}
 
     def pairs_device(self):
         """Number of (in, out) pairs of the kernel map as a device scalar (no host sync)."""
@@ -82,6 +91,40 @@ class ConvPlan:
     def num_pairs(self):
         return int(self.pairs_device().item())
 
+    def chunks(self, in_row_bytes, out_row_bytes):
+        """Batched tensors whose feature tables exceed the 2 GB extent of the buffer-addressed conv instances (64 Cfg-2
+        frames x 416 channels = 9 GB): rows are sorted by batch and the frames of a batch share no neighbours
+        (data/alivev2.py:358-383), so the layer splits into batch ranges, each with its own plan, input rows rebased to
+        the range's first row - the same (offset, channel) chain per output element, i.e. the same bits, on the FAST
+        instances.  Returns [(plan, in0, in1, out0, out1)] or None when the whole map fits (or cannot be split: one
+        frame alone beyond the extent, which then takes the guarded 64-bit form)."""
+        cm = self.cm
+        if cm is None or self.raw is None:
+            return None
+        V_in = cm.stride_map(self.in_stride).V
+        if V_in * in_row_bytes < BUF_LIMIT and self.V_out * out_row_bytes < BUF_LIMIT:
+            return None
+        bi, bo = cm.batch_bounds(self.in_stride), cm.batch_bounds(self.out_stride)
+        B = len(bi) - 1
+        f = 1
+        while f < B:
+            f *= 2
+        fits = lambda f: all((bi[min(c + f, B)] - bi[c]) * in_row_bytes < BUF_LIMIT and  # noqa: E731
+                             (bo[min(c + f, B)] - bo[c]) * out_row_bytes < BUF_LIMIT for c in range(0, B, f))
+        while f >= 1 and not fits(f):
+            f //= 2
+        if f < 1 or f >= B:
+            return None
+        if f not in self._chunked:
+            nbr, ld, mask = self.raw
+            parts = []
+            for c in range(0, B, f):
+                i0, i1, o0, o1 = bi[c], bi[min(c + f, B)], bo[c], bo[min(c + f, B)]
+                if o1 > o0:
+                    parts.append((cm._build_plan(nbr[:, o0:], ld, mask[o0:], self.K, o1 - o0, nbr_base=i0), i0, i1, o0, o1))
+            self._chunked[f] = parts
+        return self._chunked[f]
+
 
 class CoordinateManager:
     def __init__(self, device):
@@ -90,7 +133,12 @@ class CoordinateManager:
         self.parents = {}  # fine stride -> (parent int32[V_fine], child_start int32[V_coarse+1])
         self.plans = {}
         self._batch_offsets = {}
+        self._batch_bounds = {}
         self.num_batches = None
+
+    def _own(self, plan, nbr, ld, mask, in_stride, out_stride):
+        plan.cm, plan.raw, plan.in_stride, plan.out_stride = self, (nbr, ld, mask), in_stride, out_stride
+        return plan
 
     # ---- coordinate maps -------------------------------------------------------------------
     def stride_map(self, stride):
@@ -119,7 +167,19 @@ class CoordinateManager:
         return m
 
     # ---- plans -----------------------------------------------------------------------------
-    def _build_plan(self, nbr, ld, mask, K, V_out):
+    def batch_bounds(self, stride):
+        """host copy of the first row of every batch at tensor stride `stride` ([B + 1] python ints; one read-back per
+        level, cached) - the ranges batched launches are split at (ConvPlan.chunks)"""
+        if stride not in self._batch_bounds:
+            B = self.num_batches
+            if B is None:
+                m1 = self.stride_map(1)
+                B = int(m1.coords[:, 0].max().item()) + 1 if m1.V else 1
+                self.num_batches = B
+            self._batch_bounds[stride] = self.batch_offsets(stride, B).tolist()
+        return self._batch_bounds[stride]
+
+    def _build_plan(self, nbr, ld, mask, K, V_out, nbr_base=0):
         dev = self.device
         Vpad = _round_up(max(V_out, 1), SV_TILE_ROWS)
         ws_bytes = _lib.load().sv_plan_workspace_bytes(c_int64(V_out))
@@ -128,7 +188,8 @@ class CoordinateManager:
         nbr_s = torch.empty((K, Vpad), dtype=torch.int32, device=dev)
         submask = torch.empty((Vpad // SV_TILE_ROWS, K), dtype=torch.int32, device=dev)
         tile_order = torch.empty(Vpad // SV_TILE_ROWS, dtype=torch.int32, device=dev)
-        call("sv_plan_build", ptr(nbr), c_int64(ld), ptr(mask), c_int(K), c_int64(V_out), ptr(ws), c_size_t(ws_bytes),
+        call("sv_plan_build", ptr(nbr), c_int64(ld), ptr(mask), c_int(K), c_int64(V_out), c_int64(nbr_base), ptr(ws),
+             c_size_t(ws_bytes),
              ptr(perm), ptr(nbr_s), ptr(submask), ptr(tile_order), c_int64(Vpad), stream_ptr())
         return ConvPlan(perm, nbr_s, submask, tile_order, V_out, Vpad, K)
 
@@ -142,7 +203,7 @@ class CoordinateManager:
             mask = torch.empty(max(V, 1), dtype=torch.int32, device=self.device)
             call("sv_kernel_map_k3", ptr(m.coords), c_int64(V), c_int(stride), c_int(dilation), ptr(tkeys), ptr(tvals),
                  c_int64(cap), ptr(nbr), c_int64(max(V, 1)), ptr(mask), stream_ptr())
-            self.plans[key] = self._build_plan(nbr, max(V, 1), mask, 27, V)
+            self.plans[key] = self._own(self._build_plan(nbr, max(V, 1), mask, 27, V), nbr, max(V, 1), mask, stride, stride)
         return self.plans[key]
 
     def plan_down(self, stride):
@@ -158,7 +219,8 @@ class CoordinateManager:
             mask = torch.empty(max(Vc, 1), dtype=torch.int32, device=self.device)
             call("sv_kernel_map_down", ptr(fine.keys), ptr(parent), c_int64(fine.V), c_int(level), c_int64(Vc),
                  ptr(nbr), c_int64(max(Vc, 1)), ptr(mask), stream_ptr())
-            self.plans[key] = self._build_plan(nbr, max(Vc, 1), mask, 8, Vc)
+            self.plans[key] = self._own(self._build_plan(nbr, max(Vc, 1), mask, 8, Vc), nbr, max(Vc, 1), mask, stride,
+                                        stride * 2)
         return self.plans[key]
 
     def plan_up(self, stride):
@@ -178,7 +240,7 @@ class CoordinateManager:
             mask = torch.empty(max(V, 1), dtype=torch.int32, device=self.device)
             call("sv_kernel_map_up", ptr(fine.keys), ptr(parent), c_int64(V), c_int(level), ptr(nbr),
                  c_int64(max(V, 1)), ptr(mask), stream_ptr())
-            self.plans[key] = self._build_plan(nbr, max(V, 1), mask, 8, V)
+            self.plans[key] = self._own(self._build_plan(nbr, max(V, 1), mask, 8, V), nbr, max(V, 1), mask, stride, fs)
         return self.plans[key]
 
     def batch_offsets(self, stride, B):

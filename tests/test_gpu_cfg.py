@@ -245,7 +245,22 @@ def test_cfg3_batch64_fullsize_frames(gpu, oracle, cfg2):
         field = ME.TensorField(feats, coords, device=gpu)
         x = field.sparse()
         assert int(x.C[:, 0].max()) == B - 1 and x.F.shape[0] > B * 85_000
-        s_out = seg(x)
+        # 5.6M voxels x 416 channels = 9 GB per tensor: beyond the 2 GB extent of the buffer-addressed instances.  The
+        # layers run as batch ranges with their own plans (ConvPlan.chunks) / row ranges (dense layers), so EVERY launch
+        # of the wide layers must still report the FAST form - the instances the bench measures - and the chip-filling
+        # level-0/1 layers the dual-body kernel.
+        from mrcc_amd import profiling
+
+        profiling.INSTANCE_LOG = log = []
+        try:
+            s_out = seg(x)
+        finally:
+            profiling.INSTANCE_LOG = None
+        wide = [e for e in log if e[3] >= 32 and e[3] % 4 == 0 and e[4] >= 32]
+        assert wide and all(e[1]["fast"] == 1 for e in wide), [e for e in wide if e[1]["fast"] != 1][:3]
+        big = [e for e in log if e[2] == 27 and e[3] >= 384 and e[4] == 384 and e[5] > 500_000]
+        assert big and all(e[0] == "conv_fwd_dual_kernel<64, 32, 4, 3>" for e in big), big[:3]
+        assert len(log) > 70  # 61 layers; the widest ones as several ranges
         labels, _ = s_out.slice_argmax(field)
         v_out = vote(x)
         bs = x.coordinate_manager.batch_offsets(1, B).tolist()
