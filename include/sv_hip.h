@@ -202,6 +202,12 @@ int sv_slice_rows(const float* F, int64_t ld, int C, const int64_t* inverse, int
 /* label[i] = first index of the row maximum of F[inverse[i]][0..C), conf[i] = sigmoid(max). */
 int sv_slice_argmax(const float* F, int64_t ld, int C, const int64_t* inverse, int64_t N, int64_t* label,
                     float* conf, sv_stream_t stream);
+/* Key-point selection (utils/output.py:81-87 get_key_point_predictions): softmax over the C <= 32 classes of each of
+ * the N rows of `logits`, then per class c: prob[c] = max over rows of softmax[:, c], idx[c] = the LOWEST row that attains
+ * it (-1 and 0 when N = 0), selected[c] = prob[c] > conf_th.  workspace: 8 C bytes.  One pass over the logits, no host
+ * round trip between softmax, max and threshold. */
+int sv_key_point_predictions(const float* logits, int64_t ld, int C, int64_t N, float conf_th, void* workspace,
+                             size_t workspace_bytes, float* prob, int64_t* idx, int32_t* selected, sv_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A9/A10/A12  dense solves, one wavefront per problem, float64

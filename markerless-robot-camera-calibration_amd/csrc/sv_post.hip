@@ -195,6 +195,59 @@ __global__ __launch_bounds__(256) void center_scale_kernel(const float* __restri
   out[r * out_ld + c] = v;
 }
 
+// ---- key-point selection (utils/output.py:81-87): softmax over the classes of every point, then per class the highest
+//      probability over all points and the point that has it.  One thread per point: the row's softmax lives in
+//      registers; per class a wave reduction over packed (probability bits << 32 | ~index) keys - probabilities are
+//      positive floats, so their bit patterns order like the values, and among equal probabilities the LOWEST point index
+//      wins - and one 64-bit atomicMax per wave and class (max is associative and commutative: deterministic).
+template <int CMAX>
+__global__ __launch_bounds__(256) void kp_softmax_max_kernel(const float* __restrict__ logits, int64_t ld, int C,
+                                                              int64_t N, unsigned long long* __restrict__ best) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float p[CMAX];
+  const bool ok = r < N;
+  if (ok) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+      p[c] = c < C ? logits[r * ld + c] : -INFINITY;
+      m = fmaxf(m, p[c]);
+    }
+    float sum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+      p[c] = c < C ? expf(p[c] - m) : 0.0f;
+      sum += p[c];
+    }
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) p[c] = p[c] / sum;
+  }
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) {
+    if (c >= C) break;
+    unsigned long long key = 0ull;
+    if (ok && p[c] == p[c])  // a NaN row never wins
+      key = ((unsigned long long)__float_as_uint(p[c]) << 32) | (unsigned long long)(0xffffffffu - (unsigned)r);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const unsigned long long o = __shfl_xor(key, off, 64);
+      key = o > key ? o : key;
+    }
+    if ((threadIdx.x & 63) == 0 && key) atomicMax(&best[c], key);
+  }
+}
+
+__global__ void kp_finalize_kernel(const unsigned long long* __restrict__ best, int C, float conf_th,
+                                   float* __restrict__ prob, int64_t* __restrict__ idx, int32_t* __restrict__ selected) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  const unsigned long long key = best[c];
+  const float pr = key ? __uint_as_float((unsigned)(key >> 32)) : 0.0f;
+  prob[c] = pr;
+  idx[c] = key ? (int64_t)(0xffffffffu - (unsigned)(key & 0xffffffffull)) : -1;
+  selected[c] = pr > conf_th ? 1 : 0;
+}
+
 }  // namespace sv
 
 using namespace sv;
@@ -299,6 +352,28 @@ int sv_affine_act(const float* in, int64_t in_ld, int C, int64_t V, const float*
   int64_t total = V * C;
   hipLaunchKernelGGL(affine_act_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, in, in_ld, C, V,
                      scale, shift, residual, res_ld, act, slope, out, out_ld);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+int sv_key_point_predictions(const float* logits, int64_t ld, int C, int64_t N, float conf_th, void* workspace,
+                             size_t workspace_bytes, float* prob, int64_t* idx, int32_t* selected, sv_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SV_CHECK_ARG(C >= 1 && C <= 32 && ld >= C && N >= 0 && N < 0xffffffffll, "bad shape (1 <= C <= 32)");
+  SV_CHECK_ARG(prob && idx && selected && workspace, "null pointer");
+  SV_CHECK_ARG(workspace_bytes >= (size_t)C * sizeof(unsigned long long), "workspace too small (8 C bytes)");
+  unsigned long long* best = (unsigned long long*)workspace;
+  SV_HIP(hipMemsetAsync(best, 0, (size_t)C * sizeof(unsigned long long), stream));
+  if (N > 0) {
+    SV_CHECK_ARG(logits, "null pointer");
+    const dim3 grid((unsigned)((N + 255) / 256));
+    if (C <= 8)
+      hipLaunchKernelGGL(kp_softmax_max_kernel<8>, grid, dim3(256), 0, stream, logits, ld, C, N, best);
+    else
+      hipLaunchKernelGGL(kp_softmax_max_kernel<32>, grid, dim3(256), 0, stream, logits, ld, C, N, best);
+    SV_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(kp_finalize_kernel, dim3(1), dim3(32), 0, stream, best, C, conf_th, prob, idx, selected);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }

@@ -12,7 +12,29 @@ def get_segmentations_from_tensor_field(field):
 
 
 def get_key_point_predictions(logits, conf_th=0.999):
-    """softmax over classes, max over points per class, threshold (utils/output.py:81-87)."""
+    """softmax over classes, max over points per class, threshold (utils/output.py:81-87).  CUDA logits: one libsvhip
+    pass (sv_key_point_predictions: softmax in registers, per-class packed (probability, index) max) and ONE read-back of
+    the C per-class results; the reference's torch formulation leaves the device three times.  Ties take the lowest point
+    index.  Host tensors (golden vectors of the reference on CPU) keep the reference formulation."""
+    if torch.is_tensor(logits) and logits.is_cuda:
+        from ctypes import c_float, c_int, c_int64, c_size_t
+
+        from .._lib import call, ptr, stream_ptr
+
+        x = logits.detach()
+        if x.dtype != torch.float32 or x.stride(1) != 1:
+            x = x.to(torch.float32).contiguous()
+        N, C = x.shape
+        # one int64 buffer: [0, C) packed best keys (workspace), [C, 2C) indices, then C float32 probs and C int32 flags
+        buf = torch.empty(3 * C, dtype=torch.int64, device=x.device)
+        prob = buf[2 * C:].view(torch.float32)[:C]
+        sel = buf[2 * C:].view(torch.int32)[C:2 * C]
+        call("sv_key_point_predictions", ptr(x), c_int64(x.stride(0)), c_int(C), c_int64(N), c_float(conf_th), ptr(buf),
+             c_size_t(8 * C), ptr(prob), ptr(buf[C:2 * C]), ptr(sel), stream_ptr())
+        host = buf.cpu()
+        p = host[2 * C:].view(torch.float32)[:C]
+        classes = np.where(host[2 * C:].view(torch.int32)[C:2 * C].numpy() != 0)[0]
+        return host[C:2 * C].numpy()[classes], classes, p[classes]
     softmax = logits.softmax(1).max(0)
     classes = np.where(softmax[0].cpu() > conf_th)[0]
     idx = softmax[1][classes].cpu().numpy()

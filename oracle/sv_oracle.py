@@ -450,24 +450,36 @@ def _pose_mlp(sd, pooled, training=False):
     return out
 
 
-def robotnet_forward(sd, feats, frame, backbone=None):
-    """model/robotnet.py:62-83: forward_except_final -> BN+ReLU -> global max pool -> MLP -> normalise quaternion.
+def _with_joint_angles(pooled, joint_angles):
+    """model/robotnet.py:68-71: STRUCTURE.use_joint_angles concatenates the 9 joint angles behind the pooled features."""
+    if joint_angles is None:
+        return pooled
+    return np.ascontiguousarray(np.concatenate([pooled, np.asarray(joint_angles, np.float32)], axis=1))
+
+
+def robotnet_forward(sd, feats, frame, backbone=None, joint_angles=None):
+    """model/robotnet.py:62-83: forward_except_final -> BN+ReLU -> global max pool -> [cat joint angles] -> MLP
+    -> sigmoid on [:, 7:] (the three confidences of STRUCTURE.compute_confidence: out_channels = 10) -> normalise quaternion.
     backbone: the U-Net body (default MinkUNet's forward_except_final; alive_unet_forward for the fallback backbone,
     model/robotnet.py:29-30)."""
     out = (backbone or minkunet_forward_except_final)(sd, feats, frame)
     s, b = _bn(sd, "output_layer.0")
     out = affine_act(out, s, b, None, ACT_RELU)
     pooled = global_pool(out, frame.maps[1], POOL_MAX)
-    return _pose_mlp(sd, pooled)
+    return _pose_mlp(sd, _with_joint_angles(pooled, joint_angles))
 
 
-def robotnet_encode_forward(sd, feats, frame):
-    """model/robotnet_encode.py:68-119: encoder to stride 16 -> BN+ReLU -> global avg pool -> MLP."""
+def robotnet_encode_forward(sd, feats, frame, joint_angles=None, quantization_size=None):
+    """model/robotnet_encode.py:68-119: encoder to stride 16 -> BN+ReLU -> global avg pool -> [cat joint angles] -> MLP;
+    DATA.voxelize_position (eval only, :114-117): position *= quantization_size."""
     out = minkunet_encoder(sd, feats, frame)[-1]
     s, b = _bn(sd, "output_layer.0")
     out = affine_act(out, s, b, None, ACT_RELU)
     pooled = global_pool(out, frame.maps[16], POOL_AVG)
-    return _pose_mlp(sd, pooled)
+    res = _pose_mlp(sd, _with_joint_angles(pooled, joint_angles))
+    if quantization_size is not None:
+        res[:, :3] *= np.float32(quantization_size)
+    return res
 
 
 def predict_segmentation(sd, points, rgb, scale):

@@ -287,3 +287,124 @@ def test_cfg3_batch64_fullsize_frames(gpu, oracle, cfg2):
         pose_g = np.concatenate([t[b], q[b] if np.dot(q[b], pose_o[3:]) > 0 else -q[b]])
         pts_b = crops[b][0].astype(np.float64)
         assert oracle.compute_ADD_np(pts_b, pose_o, pose_g) < 1e-4  # ADD(GPU pose, oracle pose) <= 1e-4 m
+
+
+def test_cfg1_sample_frame_size_seg_bit_exact(gpu, oracle):
+    """BASELINE configs[0]: one dataset-sample-sized frame (~80k points, 2 cm voxels) through robotnet_segmentation -
+    the reference's CPU-runnable plumbing case - logits bit-exact, labels exact against the oracle."""
+    import bench
+    import mrcc_amd
+    from mrcc_amd import MinkowskiEngine as ME
+
+    model = bench.build_model(gpu)
+    pts, rgb, _ = mrcc_amd.synth.gen_room(80_000, 1.6, 11)
+    with torch.no_grad():
+        field = ME.TensorField(torch.from_numpy(rgb), torch.from_numpy(_coords(pts, 50)), device=gpu)
+        x = field.sparse()
+        out = model(x)
+        label, conf = out.slice_argmax(field)
+    ref = oracle.predict_segmentation({k: v.cpu() for k, v in model.state_dict().items()}, pts, rgb, 50)
+    assert 30_000 < x.F.shape[0] < 50_000
+    assert np.array_equal(x.coordinate_map.keys.cpu().numpy().view(np.uint64), ref["vox"]["keys"])
+    assert np.array_equal(out.F.cpu().numpy(), ref["logits"])
+    assert np.array_equal(label.cpu().numpy(), ref["label"])
+    assert np.allclose(conf.cpu().numpy(), ref["conf"], atol=1e-6)
+
+
+def test_cfg5_vote_and_pose_legs(gpu, oracle):
+    """BASELINE configs[4] beyond the seg head: a 500k-point / 1 cm labelled scene through RobotNetVote
+    (model/robotnet_vote.py:62-71; every distinct layer shape against the oracle on a row subset, as for the seg head
+    above), then the end-effector crop of that frame through the engine's stages in the reference's order
+    (app/inference_engine.py:281-382): rotation head -> translation -> key-point head -> key-point selection
+    (utils/output.py:81-87) -> Kabsch (sv_kabsch_batched), each against the oracle."""
+    import mrcc_amd
+    from mrcc_amd import MinkowskiEngine as ME
+    from mrcc_amd import nn as svnn
+    from mrcc_amd.app.inference_engine import InferenceEngine
+    from mrcc_amd.model.robotnet_vote import RobotNetVote
+    from mrcc_amd.utils import preprocess
+    from mrcc_amd.utils.config import Config
+
+    sc = mrcc_amd.synth.gen_scene(5, n_bg=480_000, n_arm=6_000, n_ee=14_000)
+    pts, rgb01 = sc["points"], sc["rgb"]
+    assert len(pts) == 500_000
+    rgb = preprocess.normalize_colors(rgb01)
+    # ---- vote leg on the whole frame
+    torch.manual_seed(8)
+    vote = RobotNetVote(3).to(gpu).eval()
+    seen = set()
+
+    def keep(sig, i):
+        if sig in seen:
+            return False
+        seen.add(sig)
+        return True
+
+    c4 = _coords(pts, 100)
+    with torch.no_grad():
+        field = ME.TensorField(torch.from_numpy(rgb), torch.from_numpy(c4), device=gpu)
+        x = field.sparse()
+        with _Recorder(svnn, keep) as rec:
+            out = vote(x)
+        vlabel, _ = out.slice_argmax(field)
+    V = x.F.shape[0]
+    assert V > 250_000 and out.F.shape == (V, 2) and torch.isfinite(out.F).all()
+    vox = oracle.voxelize(c4)
+    assert np.array_equal(x.coordinate_map.keys.cpu().numpy().view(np.uint64), vox["keys"])
+    frame, cm = oracle.Frame(vox["coords"]), x.coordinate_manager
+    rng = np.random.default_rng(6)
+    assert len(rec.calls) >= 20
+    for c in rec.calls:
+        n = min(c["V_out"], 4096 if c["sig"][2] * c["sig"][3] > 64 * 64 else 16384)
+        _check_call_rows(oracle, frame, cm, c, np.sort(rng.choice(c["V_out"], size=n, replace=False)))
+    assert np.array_equal(vlabel.cpu().numpy(), out.F.cpu().numpy().argmax(1)[vox["inverse"]])
+    del rec, out, x, field
+    # ---- pose legs on the frame's end-effector crop (ground-truth EE points: random-init labels mark no crop)
+    Config.reset()
+    Config().update({"INFERENCE": {"ROTATION": {"scale": 100}, "KEY_POINTS": {"scale": 100, "conf_threshold": 0.0},
+                                   "SEGMENTATION": {"scale": 100}}})
+    try:
+        cfg = Config()
+        eng = InferenceEngine(allow_random_init=True, seed=9)
+        ee_idx = np.where(sc["segmentation"] == 2)[0]
+        ee_pts, ee_rgb = pts[ee_idx], rgb[ee_idx]
+        assert len(ee_idx) == 14_000
+
+        def oracle_inputs(p, scale):
+            c = np.concatenate([np.zeros((len(p), 1), np.float32), (torch.from_numpy(p) * scale).numpy()], 1)
+            v = oracle.voxelize(c)
+            return v, oracle.voxel_reduce(ee_rgb, v["order"], v["seg_start"], 0)
+
+        # rotation (:446-457)
+        q = eng.predict_rotation(ee_pts, torch.from_numpy(ee_rgb))
+        p0, _ = preprocess.center_at_origin(ee_pts)
+        v, f = oracle_inputs(p0, cfg.INFERENCE.ROTATION.scale)
+        fwd = oracle.robotnet_encode_forward if cfg.INFERENCE.ROTATION.encode_only else oracle.robotnet_forward
+        want_q = fwd({k: t.cpu() for k, t in eng._rotation_model.state_dict().items()}, f, oracle.Frame(v["coords"]))[0][3:]
+        assert np.abs(q - want_q).max() < 1e-4  # north_star tolerance on pose floats
+        # translation (:459-507): pure host arithmetic on the crop and q
+        pos, _ = eng.predict_translation(ee_pts, torch.from_numpy(ee_rgb), q=q)
+        assert pos.shape == (3,) and np.isfinite(pos).all()
+        # key points (:509-559): per-point logits of the key-point head, then softmax / per-class max / threshold
+        kp_coords, kp_classes, probs = eng.predict_key_points(ee_pts, torch.from_numpy(ee_rgb))
+        v, f = oracle_inputs(p0, cfg.INFERENCE.KEY_POINTS.scale)
+        logits = oracle.robotnet_segmentation_forward(
+            {k: t.cpu() for k, t in eng._key_points_model.state_dict().items()}, f, oracle.Frame(v["coords"]))[v["inverse"]]
+        e = np.exp(logits - logits.max(1, keepdims=True))
+        sm = e / e.sum(1, keepdims=True)
+        assert list(kp_classes) == list(range(6))  # threshold 0: every class reports its best point
+        for c in range(6):
+            best = np.flatnonzero(sm[:, c] >= sm[:, c].max() - 1e-6)  # float32 softmax: accept ties within rounding
+            got_idx = np.flatnonzero((ee_pts == kp_coords[c]).all(1))
+            assert len(np.intersect1d(best, got_idx)) >= 1
+            assert abs(float(probs[c]) - sm[:, c].max()) < 1e-5
+        # Kabsch on the predicted key points (:384-393) against the oracle's SVD
+        pose = eng.predict_pose_from_kp(kp_coords, kp_classes)
+        Ro, to = oracle.get_rigid_transform_3D(mrcc_amd.synth.REFERENCE_KEY_POINTS[np.asarray(kp_classes)], np.asarray(kp_coords))
+        qo = oracle.get_q_from_matrix(Ro)
+        assert np.abs(pose[:3] - to).max() < 1e-9
+        assert min(np.abs(pose[3:] - qo).max(), np.abs(pose[3:] + qo).max()) < 1e-9
+        assert oracle.compute_ADD_np(ee_pts.astype(np.float64), np.concatenate([to, qo]),
+                                     np.concatenate([pose[:3], pose[3:] if np.dot(pose[3:], qo) > 0 else -pose[3:]])) < 1e-4
+    finally:
+        Config.reset()

@@ -250,3 +250,75 @@ def test_reference_shaped_model_code_on_the_installed_namespace(gpu):
         unfused = reference_forward(net, x)
         assert unfused.tensor_stride == 1 and torch.equal(fused.F, unfused.F)
         assert torch.equal(unfused.slice(field).F, fused.F[field.inverse_mapping])
+
+
+def test_vote_head_bit_exact_vs_oracle(gpu, oracle):
+    """A5: RobotNetVote (model/robotnet_vote.py:62-71) against the oracle's restatement of the head - not only against
+    itself (batched vs single, tests/test_gpu_cfg.py).  2 classes (ee_seg data) and 4 classes (:39)."""
+    from mrcc_amd import MinkowskiEngine as ME
+    from mrcc_amd.model.robotnet_vote import RobotNetVote
+
+    pts, rgb, lab, coords4 = _cloud(5000, 0.45, 31, 100)
+    vox, feats = _oracle_inputs(oracle, rgb, coords4)
+    for ncls, seed in ((None, 12), (4, 13)):
+        torch.manual_seed(seed)
+        model = RobotNetVote(3) if ncls is None else RobotNetVote(3, num_classes=ncls)
+        _randomize_bn(model, seed + 1)
+        model = model.to(gpu).eval()
+        sd = {k: v.cpu() for k, v in model.state_dict().items()}
+        with torch.no_grad():
+            field = ME.TensorField(torch.from_numpy(rgb), torch.from_numpy(coords4), device=gpu)
+            out = model(field.sparse())
+            votes = out.slice(field).F.cpu().numpy()
+        want = oracle.robotnet_segmentation_forward(sd, feats, oracle.Frame(vox["coords"]))
+        got = out.F.cpu().numpy()
+        assert got.shape == want.shape == (len(vox["keys"]), 2 if ncls is None else ncls)
+        assert np.array_equal(got, want), f"max diff {np.abs(got - want).max()}"
+        assert np.array_equal(votes, want[vox["inverse"]])
+
+
+def test_pose_head_config_branches(gpu, oracle):
+    """A6 branches of the pose heads that the default configuration never takes:
+    STRUCTURE.use_joint_angles (model/robotnet.py:49-50,68-71: 9 joint angles behind the pooled features),
+    STRUCTURE.compute_confidence (10 outputs, sigmoid on [:, 7:], :77) and DATA.voxelize_position
+    (model/robotnet_encode.py:100-119: position * quantization_size in eval)."""
+    from mrcc_amd import MinkowskiEngine as ME
+    from mrcc_amd.model.robotnet import make_robotnet, make_robotnet_encode
+    from mrcc_amd.utils.config import Config
+
+    parts = [_cloud(2000, 0.3, 40 + b, 100) for b in range(2)]
+    rgb = np.concatenate([p[1] for p in parts])
+    coords4 = np.concatenate([np.concatenate([np.full((len(p[0]), 1), b, np.float32), p[3][:, 1:]], axis=1)
+                              for b, p in enumerate(parts)])
+    vox, feats = _oracle_inputs(oracle, rgb, coords4)
+    ja = np.random.default_rng(3).uniform(-3, 3, size=(2, 9)).astype(np.float32)
+    Config.reset()
+    Config().update({"STRUCTURE": {"use_joint_angles": True, "compute_confidence": True},
+                     "DATA": {"voxelize_position": True, "quantization_size": 0.02}})
+    try:
+        for make, fwd, kw in ((make_robotnet, oracle.robotnet_forward, {}),
+                              (make_robotnet_encode, oracle.robotnet_encode_forward, {"quantization_size": 0.02})):
+            torch.manual_seed(21)
+            model = make("minkunet")(in_channels=3, out_channels=10)
+            assert model.pose_regression[0].in_features == model.pose_regression_input_size
+            assert model.pose_regression_input_size % 128 == 9  # 384 + 9 / 256 + 9
+            _randomize_bn(model, 22)
+            model = model.to(gpu).eval()
+            sd = {k: v.cpu() for k, v in model.state_dict().items()}
+            with torch.no_grad():
+                x = ME.TensorField(torch.from_numpy(rgb), torch.from_numpy(coords4), device=gpu).sparse()
+                got = model((x, torch.from_numpy(ja).to(gpu))).cpu().numpy()
+            want = fwd(sd, feats, oracle.Frame(vox["coords"]), joint_angles=ja, **kw)
+            assert got.shape == want.shape == (2, 10)
+            assert np.allclose(got, want, atol=1e-4, rtol=0), f"max diff {np.abs(got - want).max()}"
+            assert ((got[:, 7:] > 0) & (got[:, 7:] < 1)).all()  # confidences went through the sigmoid
+            assert np.allclose(np.linalg.norm(got[:, 3:7], axis=1), 1.0, atol=1e-5)
+            if kw:  # the position really was scaled: undo it and compare with the unscaled oracle
+                raw = fwd(sd, feats, oracle.Frame(vox["coords"]), joint_angles=ja)
+                assert np.allclose(got[:, :3], raw[:, :3] * np.float32(0.02), atol=1e-5)
+            # joint angles matter: a different vector moves the output
+            with torch.no_grad():
+                other = model((x, torch.from_numpy(ja[::-1].copy()).to(gpu))).cpu().numpy()
+            assert np.abs(other - got).max() > 1e-6
+    finally:
+        Config.reset()
