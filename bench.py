@@ -389,23 +389,232 @@ def hbm_bound_layers(model, device, iters=60):
 
 
 def launcher_selftest(args, world, rank):
-    """What the N-rank launch does around the GPU work, on the CPU: init (gloo), rank r takes frames r, r + world, ...,
-    ONE all_gather of the metrics record, max-over-ranks time, rank 0 prints the line."""
+    """What the N-rank launch does around the GPU work, on the CPU: pin the rank, init (gloo), rank r takes frames
+    r, r + world, ... (weak: --steps frames per rank; strong: --total-frames in all), R repeats of a fake timed region,
+    ONE all_gather of the metrics record, max-over-ranks time per repeat, rank 0 prints the line.
+    --selftest-fail-rank R: that rank exits non-zero before the rendezvous (the launcher must relay the failure)."""
     import torch.distributed as dist
-    from mrcc_amd.app.sharding import frame_seeds_for_rank, gather_metrics
+    from mrcc_amd.app.sharding import frame_seeds_for_rank, gather_metrics, ordered_prefetch, pin_rank
 
+    if args.selftest_fail_rank is not None and rank == args.selftest_fail_rank:
+        sys.stderr.write(f"bench.py selftest: rank {rank} fails on purpose\n")
+        sys.exit(3)
+    pin = pin_rank(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     if world > 1:
         dist.init_process_group("gloo")
-    seeds = frame_seeds_for_rank(args.steps * world, rank, world)
-    agg = gather_metrics({"frames": len(seeds), "elapsed": 0.001 * (rank + 1), "confusion": np.eye(3, dtype=np.int64),
-                          "seed_sum": int(sum(seeds))}, device="cpu")
+    total = args.total_frames if args.total_frames > 0 else args.steps * world
+    seeds = frame_seeds_for_rank(total, rank, world)
+    # the strong mode's frame source: seeds of this rank through the background host threads, in order
+    produced = list(ordered_prefetch(lambda s_: s_ * 2, seeds, threads=2))
+    assert produced == [2 * s_ for s_ in seeds]
+    reps = [0.001 * (rank + 1) * (1 + 0.1 * r) for r in range(args.repeats)]
+    agg = gather_metrics({"frames": len(seeds), "elapsed": reps[0], "confusion": np.eye(3, dtype=np.int64),
+                          "seed_sum": int(sum(seeds)), "elapsed_repeats": reps}, device="cpu")
     if rank == 0:
         print(json.dumps({"metric": "launcher selftest (no GPU work)", "n_gpus": world, "steps": args.steps,
+                          "scaling": "strong" if args.total_frames > 0 else "weak",
                           "frames": agg["frames"], "per_rank_frames": agg["per_rank_frames"],
-                          "seed_sum": agg["seed_sum"], "elapsed_max": agg["elapsed_max"], "selftest": True}), flush=True)
+                          "seed_sum": agg["seed_sum"], "elapsed_max": agg["elapsed_max"],
+                          "elapsed_repeats_max": agg["elapsed_repeats_max"], "pinned_cores": pin.get("cores"),
+                          "selftest": True}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _median(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
+
+
+def strong_scaling_block(model, device, rank, world, total_frames, streams, threads, barrier):
+    """Cfg-4 (BASELINE configs[3]): a FIXED job of `total_frames` frames sharded over the ranks (rank r takes seeds
+    r, r + world, ...: app/sharding.py), host arrays in -> labels out.  Inside the timed region, per rank: background
+    host threads produce the rank's frames in order (synthetic generation stands in for the reference's per-frame
+    loader, test_segmentation.py:58-73), each frame is staged through pinned memory, uploaded, voxelised, run through
+    the network, and its labels are copied back (app/pipeline.py HostFrameStream) - so host-side cost, the one thing that
+    can break scaling on a shared host, is inside the measurement.  Returns this rank's record."""
+    from mrcc_amd.app.pipeline import HostFrameStream
+    from mrcc_amd.app.sharding import frame_seeds_for_rank, ordered_prefetch
+
+    seeds = frame_seeds_for_rank(total_frames, rank, world)
+
+    def stage(x, field):
+        return model(x).slice_argmax(field, with_conf=False)[0]
+
+    stream = HostFrameStream(device, SCALE, stage, None, compute_streams=streams)
+
+    def source(which):
+        return ordered_prefetch(lambda sd: mrcc_amd.synth.gen_room(POINTS, ROOM, sd)[:2], which, threads=threads,
+                                lookahead=2 * threads + 2)
+
+    for _ in stream.run(source(seeds[:min(4, len(seeds))])):  # warm the pinned buffers and the source's threads
+        pass
+    torch.cuda.synchronize()
+    barrier()
+    hist = np.zeros(3, dtype=np.int64)
+    t0 = time.perf_counter()
+    n = 0
+    for labels in stream.run(source(seeds)):
+        hist += np.bincount(labels, minlength=3)[:3]
+        n += 1
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    hs = stream.host_s
+    return {"frames": n, "elapsed": elapsed, "hist": hist, "seed_sum": int(sum(seeds)),
+            "host_ms_per_frame": {k: round(v / max(hs["frames"], 1) * 1e3, 3) for k, v in hs.items() if k != "frames"}}
+
+
+def other_configs_block(model, device, streams, checked):
+    """BASELINE configs[2] and [4] on the driver-run line (bounded: a few seconds each), each with a parity flag.
+      cfg5: 500k points / 1 cm frames through the headline pipeline (voxelise + maps + U-Net + slice/argmax) - frames/s;
+            parity = voxel keys equal the oracle's, the last dense layers of the head bit-exact against the oracle on
+            the GPU's own input rows, labels = argmax of the logits.
+      cfg3: 64 Cfg-2 frames in ONE sparse tensor (batch column, data/alivev2.py:358-383: 12.8 M points, 5.6 M voxels) -
+            seg forward + 64 Kabsch problems, frames/s; parity = the batch's frame 0 equals the one-frame run bit for
+            bit (and, through it, the oracle's labels when the accuracy block checked that frame); every launch of the
+            wide layers on the buffer-addressed (FAST) instances although the tensors exceed 2 GB."""
+    import sv_oracle as O
+    from mrcc_amd.app.pipeline import FramePipeline
+    from mrcc_amd.utils import transformation as T
+
+    out = {}
+    # ---- Cfg-5
+    _log("other configs: cfg5 (500k points, 1 cm)")
+    frames5 = []
+    for sd in range(2):
+        pts, rgb, _ = mrcc_amd.synth.gen_room(500_000, ROOM, sd)
+        c4 = np.concatenate([np.zeros((len(pts), 1), np.float32), pts * np.float32(100)], axis=1)
+        frames5.append((torch.from_numpy(c4).to(device), torch.from_numpy(rgb).to(device), c4))
+    pipe = FramePipeline(device, levels=4, compute_streams=streams)
+    with torch.no_grad():
+        run_frames(model, pipe, frames5, 4)
+        pipe.drain()
+        torch.cuda.synchronize()
+        n5 = 10
+        t0 = time.perf_counter()
+        vox5 = run_frames(model, pipe, frames5, n5)
+        torch.cuda.synchronize()
+        dt5 = (time.perf_counter() - t0) / n5
+        # parity on frame 0
+        field = ME.TensorField(frames5[0][1], frames5[0][0], device=device)
+        x = field.sparse()
+        feats = model.forward_except_final(x)
+        h0 = model.final.forward_fused(feats, act=2, slope=model.leaky_relu.negative_slope)
+        h1 = model.regression[0].forward_fused(h0, act=2, slope=model.regression[1].negative_slope)
+        logits = model.regression[2].forward_fused(h1)
+        label, _ = logits.slice_argmax(field)
+        vox = O.voxelize(frames5[0][2])
+        rows = np.sort(np.random.default_rng(0).choice(x.F.shape[0], size=2048, replace=False))
+        ridx = torch.from_numpy(rows).to(device)
+        sd_ = {k: v.cpu() for k, v in model.state_dict().items()}
+        w0 = sd_["final.kernel"].numpy()[None]
+        o0 = O.conv(feats.F[ridx].cpu().numpy(), w0, None, len(rows), None, sd_["final.bias"].numpy().reshape(-1), None,
+                    O.ACT_LEAKY, 0.01)
+        o1 = O.conv(o0, sd_["regression.0.linear.weight"].numpy().T[None], None, len(rows), None,
+                    sd_["regression.0.linear.bias"].numpy(), None, O.ACT_LEAKY, 0.01)
+        o2 = O.conv(o1, sd_["regression.2.linear.weight"].numpy().T[None], None, len(rows), None,
+                    sd_["regression.2.linear.bias"].numpy())
+        lg = logits.F.cpu().numpy()
+        out["cfg5"] = {
+            "workload": "cfg5: 500k-pt cloud, 1 cm voxels, seg U-Net forward (voxelise + maps + U-Net + slice/argmax)",
+            "value": round(1.0 / dt5, 3), "unit": "frames/s", "ms_per_frame": round(dt5 * 1e3, 3), "frames_timed": n5,
+            "active_voxels_per_frame": int(vox5 // n5),
+            "parity": {"voxel_keys_equal": bool(np.array_equal(x.coordinate_map.keys.cpu().numpy().view(np.uint64), vox["keys"])),
+                       "inverse_equal": bool(np.array_equal(field.inverse_mapping.cpu().numpy(), vox["inverse"])),
+                       "head_layers_bit_exact_on_2048_rows": bool(np.array_equal(lg[rows], o2)),
+                       "labels_are_argmax": bool(np.array_equal(label.cpu().numpy(), lg.argmax(1)[vox["inverse"]])),
+                       "note": "vote and pose legs at this size: tests/test_gpu_cfg.py::test_cfg5_vote_and_pose_legs"}}
+        del frames5, pipe, field, x, feats, h0, h1, logits
+        torch.cuda.empty_cache()
+        # ---- Cfg-3
+        B = 64
+        _log(f"other configs: cfg3 ({B} frames in one sparse tensor)")
+        coords, feats_in, *_ = make_frame(0, device, batch=B)
+        crops = [mrcc_amd.synth.gen_ee_crop(sd, n=16) for sd in range(B)]
+        kp_ref = np.repeat(mrcc_amd.synth.REFERENCE_KEY_POINTS[None], B, axis=0)
+        kp_tgt = np.stack([c[3] for c in crops])
+
+        def step3():
+            f = ME.TensorField(feats_in, coords, device=device)
+            xs = f.sparse()
+            o = model(xs)
+            lab = o.slice_argmax(f)[0]
+            R, t, q = T.get_rigid_transform_3D_batched(kp_ref, kp_tgt, device=device)
+            return xs, o, lab, (R, t, q)
+
+        profiling.INSTANCE_LOG = log = []
+        xs, o, lab, pose = step3()
+        profiling.INSTANCE_LOG = None
+        torch.cuda.synchronize()
+        wide = [e for e in log if e[3] >= 32 and e[3] % 4 == 0 and e[4] >= 32]
+        bs = xs.coordinate_manager.batch_offsets(1, B).tolist()
+        f1 = ME.TensorField(feats_in[:POINTS], coords[:POINTS], device=device)
+        x1 = f1.sparse()
+        o1_ = model(x1)
+        l1 = o1_.slice_argmax(f1)[0]
+        same = bool(torch.equal(o.F[bs[0]:bs[1]], o1_.F) and torch.equal(lab[:POINTS], l1))
+        oracle_labels = None
+        if checked is not None and checked["what"].startswith("full frame"):
+            oracle_labels = bool(np.array_equal(lab[:POINTS].cpu().numpy(), checked["ref"]["label"]))
+        Ro, to = O.get_rigid_transform_3D(kp_ref[0], kp_tgt[0])
+        V3 = xs.F.shape[0]
+        del xs, o, lab, x1, o1_, f1
+        t0 = time.perf_counter()
+        n3 = 2
+        for _ in range(n3):
+            step3()
+        torch.cuda.synchronize()
+        dt3 = (time.perf_counter() - t0) / n3
+        out["cfg3"] = {
+            "workload": f"cfg3: {B} synthetic 200k-pt frames in ONE sparse tensor (batch column), seg U-Net forward + "
+                        f"slice/argmax + {B} Kabsch problems",
+            "value": round(B / dt3, 3), "unit": "frames/s", "ms_per_batch": round(dt3 * 1e3, 2), "batches_timed": n3,
+            "active_voxels": int(V3),
+            "parity": {"frame0_equals_single_frame_run_bit_exact": same, "frame0_labels_equal_oracle": oracle_labels,
+                       "all_wide_layer_launches_on_fast_instances": bool(wide and all(e[1]["fast"] == 1 for e in wide)),
+                       "conv_launches": len(log),
+                       "kabsch_max_abs_dR_vs_oracle": float(np.abs(pose[0][0] - Ro).max())}}
+        del coords, feats_in
+        torch.cuda.empty_cache()
+    return out
+
+
+def engine_block(device):
+    """Secondary configuration through the REFERENCE'S API: InferenceEngine.predict_segmentation_stream, host numpy arrays
+    in -> per-point labels out (pinned staging, H2D, voxelisation, network, largest-cluster rule, D2H all inside the timed
+    region; app/inference_engine.py, app/pipeline.py HostFrameStream), beside the synchronous per-frame call."""
+    from mrcc_amd.app.inference_engine import InferenceEngine
+    from mrcc_amd.utils.config import Config
+
+    Config.reset()
+    Config().update({"INFERENCE": {"SEGMENTATION": {"scale": SCALE}}})
+    try:
+        eng = InferenceEngine(allow_random_init=True, seed=1)
+        pool = [mrcc_amd.synth.gen_room(POINTS, ROOM, sd)[:2] for sd in range(4)]
+        frames = [pool[i % 4] for i in range(32)]
+        ref = eng.predict_segmentation(*pool[1])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(6):
+            eng.predict_segmentation(*frames[i])
+        torch.cuda.synchronize()
+        sync_ms = (time.perf_counter() - t0) / 6 * 1e3
+        list(eng.predict_segmentation_stream(iter(frames[:8])))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        got = list(eng.predict_segmentation_stream(iter(frames)))
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / len(frames) * 1e3
+        return {"workload": "engine: InferenceEngine.predict_segmentation_stream, host numpy in -> labels out "
+                            "(H2D, voxelise, U-Net, slice/argmax, EE cluster rule, D2H inside the timed region), 200k-pt frames",
+                "value": round(1e3 / ms, 3), "unit": "frames/s", "ms_per_frame": round(ms, 3), "frames_timed": len(frames),
+                "per_frame_predict_segmentation_ms": round(sync_ms, 3),
+                "labels_equal_predict_segmentation": bool(np.array_equal(got[1], ref) and np.array_equal(got[5], ref))}
+    finally:
+        Config.reset()
 
 
 def main():
@@ -413,23 +622,35 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region (exactly --steps steps between barrier + synchronize) is run this many times; "
+                         "ms_per_step is the median, min / max are on the line.  More repeats are added until the timed "
+                         "regions total >= 1 s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pool", type=int, default=4, help="distinct frames resident per rank")
     ap.add_argument("--no-kernel-timer", action="store_true", help="diagnostic: drop the per-launch HIP events")
-    ap.add_argument("--streams", type=int, default=4,
-                    help="compute streams alternating between frames, level-0 stages taking turns (app/pipeline.py).  "
-                         "frames/s and the dominant layer's per-launch fraction of the matrix peak in the timed region "
-                         "(tools/ab_env_roof.sh): 1 stream 55 / 0.73, 2: 61.7 / 0.61, 3: 64.2 / 0.50, 4: 63.4 / 0.58, "
-                         "5: 63.8 / 0.55 - every frame in flight stretches the launches it shares the chip with")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="compute streams alternating between frames (app/pipeline.py); default = the configuration with "
+                         "the best measured frames/s (DESIGN.md section 8)")
+    ap.add_argument("--stagger-level0", type=int, default=None, choices=(0, 1),
+                    help="level-0 stages of consecutive frames take turns (default: MRCC_STAGGER_LEVEL0 / the pipeline's default)")
     ap.add_argument("--frames-per-step", type=int, default=1,
                     help="frames fused into one sparse tensor per step (batch column); 1 = the headline workload")
     ap.add_argument("--batched-frames", type=int, default=4,
                     help="secondary measurement: this many frames per step in one sparse tensor (0/1 = skip)")
+    ap.add_argument("--total-frames", type=int, default=0,
+                    help="STRONG-scaling mode (Cfg-4): a fixed job of this many frames sharded over the ranks, host arrays "
+                         "in -> labels out, frame source and H2D inside the timed region; becomes the headline of the line")
+    ap.add_argument("--strong-frames", type=int, default=512,
+                    help="frames of the secondary strong-scaling block of a default (weak) run; 0 = skip")
+    ap.add_argument("--source-threads", type=int, default=0, help="host threads producing frames in the strong mode (0 = auto)")
     ap.add_argument("--no-extras", action="store_true",
-                    help="headline measurement only: no batched configuration, no HBM-bound-layer block (PMC passes)")
+                    help="headline measurement only: no batched / other-config / engine / strong blocks, no HBM-bound-layer "
+                         "block (PMC passes)")
     ap.add_argument("--launcher-selftest", action="store_true",
-                    help="CPU rehearsal of the N-rank launch: rendezvous (gloo), frame sharding, the one all_gather and "
-                         "the JSON line, without touching a GPU (tests/test_dist_cpu.py)")
+                    help="CPU rehearsal of the N-rank launch: pinning, rendezvous (gloo), frame sharding (weak or strong), "
+                         "the one all_gather and the JSON line, without touching a GPU (tests/test_dist_cpu.py)")
+    ap.add_argument("--selftest-fail-rank", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--gather-gemm-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gather_gemm_child:
@@ -448,6 +669,12 @@ def main():
     backend = os.environ.get("MRCC_DIST_BACKEND", "nccl")  # "gloo" = rehearsal with several ranks on one GPU
     if args.launcher_selftest:
         return launcher_selftest(args, world, rank)
+    # ---- host placement, BEFORE the first GPU call (no re-exec): this rank's threads stay on its GPU's NUMA node
+    from mrcc_amd.app.sharding import gather_metrics, pin_rank
+
+    full_affinity = os.sched_getaffinity(0)
+    pin = pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))) if world > 1 else \
+        {"pinned": False, "reason": "single rank: left on the whole host", "cores": len(full_affinity)}
     dev_index = local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         import torch.distributed as dist
@@ -462,18 +689,54 @@ def main():
     torch.cuda.set_device(device)
     mrcc_amd._lib.load()
 
-    _log(f"rank {rank}/{world} on {device}: building the model and {args.pool} resident frames")
-    model = build_model(device)
-    # rank r owns frames r, r + world, ... of the global seed sequence (Cfg-4 sharding rule, SURVEY.md §8d)
-    frames = [make_frame(rank + world * i, device, batch=args.frames_per_step) for i in range(args.pool)]
-
     def barrier():
         if world > 1:
             dist.barrier()
 
+    _log(f"rank {rank}/{world} on {device} ({pin}): building the model and {args.pool} resident frames")
+    model = build_model(device)
+    # ---- the oracle pass comes FIRST, outside every timed region: the reference labels of the accuracy half of the metric
+    #      (every N) and, at N = 1, the timed CPU baseline.  With N > 1 it is capped to the quarter frame (~2.5 s) so that
+    #      the other ranks wait at the first barrier for seconds, not for the 17 s of the full N = 1 pass.
+    base = base_mm = checked = None
+    if rank == 0 and not args.no_cpu_baseline:
+        base, base_mm, checked = oracle_pass(model, budget_s=25.0 if world == 1 else 0.0, world=world)
+    # rank r owns frames r, r + world, ... of the global seed sequence (Cfg-4 sharding rule, SURVEY.md §8d)
+    frames = [make_frame(rank + world * i, device, batch=args.frames_per_step) for i in range(args.pool)]
+
     from mrcc_amd.app.pipeline import FramePipeline
 
-    pipe = FramePipeline(device, levels=4, compute_streams=args.streams)
+    stagger = None if args.stagger_level0 is None else bool(args.stagger_level0)
+    pipe = FramePipeline(device, levels=4, compute_streams=args.streams, stagger_level0=stagger)
+    src_threads = args.source_threads or max(2, min(6, pin.get("cores", 8) - 2))
+    if args.total_frames > 0:
+        # ------------------------------------------------------------------------------------------------ strong mode
+        with torch.no_grad():
+            rec = strong_scaling_block(model, device, rank, world, args.total_frames, args.streams, src_threads, barrier)
+        agg = gather_metrics({"frames": rec["frames"], "elapsed": rec["elapsed"], "confusion": np.diag(rec["hist"]),
+                              "seed_sum": rec["seed_sum"]}, device=device if backend == "nccl" else "cpu")
+        if rank == 0:
+            t_max = agg["elapsed_max"]
+            line = {"metric": "point-cloud frames/sec at 200k pts/frame", "value": round(agg["frames"] / t_max, 3),
+                    "unit": "frames/s", "n_gpus": world, "steps": max(agg["per_rank_frames"]), "warmup": 4,
+                    "ms_per_step": round(t_max / max(agg["per_rank_frames"]) * 1e3, 3), "higher_is_better": True,
+                    "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                    "config": {"workload": f"cfg4: a fixed job of {args.total_frames} synthetic 200k-pt frames (2 cm voxels) "
+                                           f"sharded over the ranks, host arrays in -> labels out: frame source ({src_threads} "
+                                           "host threads per rank), pinned staging, H2D, voxelise, RobotNetSegmentation"
+                                           "(MinkUNet18D), slice/argmax, D2H all inside the timed region",
+                               "total_frames": args.total_frames, "per_rank_frames": agg["per_rank_frames"],
+                               "points_per_frame": POINTS, "label_histogram": [int(v) for v in np.diag(agg["confusion"])],
+                               "host_ms_per_frame_rank0": rec["host_ms_per_frame"], "host_placement": pin,
+                               "parallelism": f"frame-sharded x{world} (rank r: seeds r, r + {world}, ...), one all_gather "
+                                              "of metrics"},
+                    "roofline": None, "cpu_baseline": base}
+            print(json.dumps(line), flush=True)
+        faulthandler.cancel_dump_traceback_later()
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     with torch.no_grad():
         # warm-up (untimed), part 1 on ONE compute stream: every conv launch is event-timed -> per-kernel table and the
         # dominant kernel instance measured in isolation; part 2 warms the multi-stream pipeline used in the timed region
@@ -498,38 +761,58 @@ def main():
         run_frames(model, pipe, frames, nwarm, warm_hist)
         pipe.drain()
         torch.cuda.synchronize()
-        timer = profiling.KernelTimer(capacity=2 * 32 * args.steps + 64)
-        timer.only = {dominant}
-        profiling.TIMER = None if args.no_kernel_timer else timer
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        _log(f"warm-up done; timing {args.steps} steps")
-        t0 = time.perf_counter()
-        hist = torch.zeros(3, dtype=torch.int64, device=device)
-        voxels = run_frames(model, pipe, frames, args.steps, hist)
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        profiling.TIMER = None
-    _log(f"timed region: {elapsed * 1e3 / args.steps:.2f} ms/step")
-    # ---- secondary, separately named configuration: B frames fused into one sparse tensor per step (batch column,
-    #      data/alivev2.py:358-383) through the same pipeline; the headline above stays one frame per step
+        # ---- the timed region, R times: each is EXACTLY --steps steps bracketed by barrier + synchronize on both sides
+        elapsed_list, voxels, hist, timer = [], 0, None, None
+
+        def timed_region():
+            nonlocal voxels, hist, timer
+            timer_r = profiling.KernelTimer(capacity=2 * 32 * args.steps + 64)
+            timer_r.only = {dominant}
+            profiling.TIMER = None if args.no_kernel_timer else timer_r
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            hist_r = torch.zeros(3, dtype=torch.int64, device=device)
+            voxels = run_frames(model, pipe, frames, args.steps, hist_r)
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            elapsed_list.append(time.perf_counter() - t0)
+            profiling.TIMER = None
+            if timer is None:
+                timer, hist = timer_r, hist_r
+            else:
+                timer.records += timer_r.records
+
+        repeats = max(1, args.repeats)
+        _log(f"warm-up done; timing {args.steps} steps x {repeats} repeats")
+        for _ in range(repeats):
+            timed_region()
+        # short regions (small --steps): more repeats until the timed regions total >= 1 s.  The count must be identical on
+        # every rank (each repeat contains barriers), so rank 0 decides and broadcasts it.
+        need = int(math.ceil(1.0 / max(sum(elapsed_list) / len(elapsed_list), 1e-6)))
+        if world > 1:
+            t = torch.tensor([need], dtype=torch.int64, device=device if backend == "nccl" else "cpu")
+            dist.broadcast(t, 0)
+            need = int(t.item())
+        for _ in range(min(need, 50) - repeats):
+            timed_region()
+    elapsed = _median(elapsed_list)
+    _log(f"timed regions: median {elapsed * 1e3 / args.steps:.2f} ms/step over {len(elapsed_list)} repeats "
+         f"(min {min(elapsed_list) * 1e3 / args.steps:.2f}, max {max(elapsed_list) * 1e3 / args.steps:.2f})")
+    # ---- secondary, separately named configurations (N = 1 only: with more ranks they would only make the others wait)
+    extras = world == 1 and not args.no_extras and args.frames_per_step == 1
     batched = None
-    if args.batched_frames > 1 and args.frames_per_step == 1 and not args.no_extras:
+    if extras and args.batched_frames > 1:
         bsteps = max(4, args.steps // args.batched_frames)
         with torch.no_grad():
             bframes = [make_frame(rank + world * i, device, batch=args.batched_frames) for i in range(2)]
             run_frames(model, pipe, bframes, 3)
             pipe.drain()
             torch.cuda.synchronize()
-            barrier()
-            torch.cuda.synchronize()
             tb = time.perf_counter()
             run_frames(model, pipe, bframes, bsteps)
-            torch.cuda.synchronize()
-            barrier()
             torch.cuda.synchronize()
             tb = time.perf_counter() - tb
             del bframes
@@ -537,15 +820,27 @@ def main():
                    "frames_per_step": args.batched_frames, "steps": bsteps, "ms_per_step": round(tb / bsteps * 1e3, 3),
                    "value_this_rank": round(bsteps * args.batched_frames / tb, 3), "unit": "frames/s"}
         _log(f"batched x{args.batched_frames}: {batched['value_this_rank']} frames/s on this rank")
-    hbm_layers = hbm_bound_layers(model, device) if (rank == 0 and not args.no_extras) else None
+    hbm_layers = hbm_bound_layers(model, device) if extras else None
+    other = engine = None
+    if extras:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        other = other_configs_block(model, device, args.streams, checked)
+        _log("engine block: InferenceEngine.predict_segmentation_stream")
+        engine = engine_block(device)
+    # the strong-scaling block runs at EVERY N (same total job), so the driver's N = 1, 2, 4, 8 lines carry the curve
+    strong = None
+    if not args.no_extras and args.strong_frames > 0 and args.frames_per_step == 1:
+        _log(f"strong-scaling block: {args.strong_frames} frames over {world} rank(s), {src_threads} source threads per rank")
+        with torch.no_grad():
+            strong = strong_scaling_block(model, device, rank, world, args.strong_frames, args.streams, src_threads, barrier)
 
     # the run's ONE collective: all_gather of a small per-rank record (RCCL over xGMI when world > 1)
-    from mrcc_amd.app.sharding import gather_metrics
-
     h = hist.cpu().numpy()
-    agg = gather_metrics({"frames": args.steps * args.frames_per_step, "elapsed": elapsed, "confusion": np.diag(h), "seed_sum": voxels},
-                         device=device if backend == "nccl" else "cpu")
-    t_max = agg["elapsed_max"]
+    rec = {"frames": args.steps * args.frames_per_step, "elapsed": elapsed, "confusion": np.diag(h), "seed_sum": voxels,
+           "elapsed_repeats": elapsed_list + ([strong["elapsed"], float(strong["frames"])] if strong else [])}
+    agg = gather_metrics(rec, device=device if backend == "nccl" else "cpu")
+    reps_max = agg["elapsed_repeats_max"][:len(elapsed_list)]
+    t_med = _median(reps_max)
     total_frames = float(agg["frames"])
     voxels_per_frame = voxels // max(args.steps * args.frames_per_step, 1)
 
@@ -553,17 +848,23 @@ def main():
         ksum = timer.summarize()
         ksum_by_layer = timer.summarize(by_layer=True)
         roofline = None
+        nwarm = max(args.warmup, 2)
+        gflop_step = sum(v["flops"] for v in warm.values()) / nwarm / 1e9  # every conv launch of one step
         if dominant_layer in ksum_by_layer:
             name, d = dominant, ksum_by_layer[dominant_layer]
-            _, lK, lCin, lCout, lrows = dominant_layer
+            _, lK, lCin, lCout, lwhere = dominant_layer
             tflops = d["flops"] / (d["ms"] * 1e-3) / 1e12
             roofline = {
-                "kernel": name, "layer": f"kernel volume {lK}, {lCin} -> {lCout} channels, output map {lrows} (s<tensor stride>)",
+                "kernel": name, "layer": f"kernel volume {lK}, {lCin} -> {lCout} channels, output map {lwhere} "
+                                         "(s<tensor stride>: s1 = level 0)",
                 "bound": "mfma", "achieved": round(tflops, 3), "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                 "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                 "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
                 "compute_streams": args.streams,
+                "note": "achieved / frac = per-launch HIP-event intervals INSIDE the timed regions, where a launch shares "
+                        "the chip with the other frames' kernels; `isolated` = the same launches alone on the GPU; "
+                        "`end_to_end` = all algorithmic flops of a step / ms_per_step",
             }
             # HBM traffic of this kernel from PMC counters (separate rocprofv3 --pmc passes over this command, calibrated
             # on a known-traffic launch as the MI355X guide prescribes): newest profiles/rNN_traffic.json, GB per launch
@@ -579,13 +880,14 @@ def main():
                     want_grid = rows / 64.0 * 2.3  # 64-row tiles x 2 column halves + 15 % of the tiles at half height
                     tr = min(groups, key=lambda g: abs(math.log(g["grid_workgroups"] / want_grid)))
                 if tr:
+                    alg_gb = warm_by_layer[dominant_layer]["bytes"] / warm_by_layer[dominant_layer]["launches"] / 1e9
                     roofline["traffic"] = tr["traffic_GB_per_launch"]
                     roofline["traffic_unit"] = "GB per launch (PMC, calibrated)"
                     roofline["traffic_source"] = {"file": "profiles/" + os.path.basename(tfile),
                                                   "collected_at_commit": tj.get("commit", "unknown")}
-                    roofline["algorithmic_GB_per_launch"] = round(
-                        warm_by_layer[dominant_layer]["bytes"] / warm_by_layer[dominant_layer]["launches"] / 1e9, 4)
-            except (OSError, KeyError, ValueError):
+                    roofline["algorithmic_GB_per_launch"] = round(alg_gb, 4)
+                    roofline["traffic_over_algorithmic"] = round(tr["traffic_GB_per_launch"] / alg_gb, 2)
+            except (OSError, KeyError, ValueError, IndexError):
                 pass
             # every launch of that kernel instance in the timed region, whatever the layer (levels 0 and 1, K = 27 and 8,
             # Cin 384 and 416): the aggregate the roofline object carried before it was split by layer shape
@@ -599,35 +901,59 @@ def main():
             # streams the timed-region duration of a launch includes the time it shares the CUs with the other frame
             roofline["isolated"] = {"achieved": round(iso_tf, 3), "frac": round(iso_tf / PEAK_F32_MFMA_TFLOPS, 4),
                                     "avg_launch_ms": round(iso["ms"] / iso["launches"], 4)}
-        nwarm = max(args.warmup, 2)
+            # the whole step against the matrix peak: every conv launch's algorithmic flops (2 P Cin Cout, warm-up pass,
+            # where all of them are counted) over the median ms_per_step of this rank's timed regions
+            e2e = gflop_step / (elapsed / args.steps * 1e3) if elapsed > 0 else 0.0  # GFLOP / ms = TFLOP/s
+            roofline["end_to_end"] = {"gflop_per_step": round(gflop_step, 1), "tflops": round(e2e, 2),
+                                      "frac": round(e2e / PEAK_F32_MFMA_TFLOPS, 4)}
         kernels = {k: {"launches_per_step": v["launches"] // nwarm, "ms_per_step": round(v["ms"] / nwarm, 3),
                        "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                        "gather_GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for k, v in warm.items()}
+        per_step = [t / args.steps * 1e3 for t in reps_max]
         line = {
-            "metric": "point-cloud frames/sec at 200k pts/frame", "value": round(total_frames / t_max, 3),
+            "metric": "point-cloud frames/sec at 200k pts/frame", "value": round(total_frames / t_med, 3),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(t_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(t_med / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "repeats": {"n": len(per_step), "ms_per_step_median": round(_median(per_step), 3),
+                        "ms_per_step_min": round(min(per_step), 3), "ms_per_step_max": round(max(per_step), 3),
+                        "timed_seconds_total": round(sum(reps_max), 3),
+                        "note": "each repeat = exactly `steps` steps between barrier + synchronize, max over ranks; value and "
+                                "ms_per_step are the MEDIAN repeat"},
             "config": {"workload": "cfg2: synthetic 200k-pt RGB-D cloud, 2 cm voxels, RobotNetSegmentation(MinkUNet18D) "
                                    "forward = voxelise + sparse U-Net + slice/argmax, random-init weights",
                        "points_per_frame": POINTS, "frames_per_step": args.frames_per_step,
                        "voxel_size_m": 1.0 / SCALE,
                        "active_voxels_per_frame": int(voxels_per_frame),
                        "label_histogram": [int(x) for x in np.diag(agg["confusion"])],
+                       "host_placement": pin,
                        "parallelism": f"frame-sharded x{world}, one RCCL all_gather of metrics; per rank: prep stream + "
                                       f"{args.streams} compute stream(s) alternating between frames"},
             "roofline": roofline,
             "kernels_warmup": kernels,
         }
+        if strong is not None:
+            extra = agg["elapsed_repeats_max"][len(elapsed_list):]
+            t_strong = extra[0]
+            line["strong_scaling"] = {
+                "workload": f"cfg4: a FIXED job of {args.strong_frames} synthetic 200k-pt frames sharded over {world} rank(s) "
+                            "(rank r: seeds r, r + N, ...), host arrays in -> labels out; frame source, pinned staging, H2D "
+                            "and D2H inside the timed region",
+                "scaling": "strong", "total_frames": args.strong_frames, "value": round(args.strong_frames / t_strong, 3),
+                "unit": "frames/s", "seconds": round(t_strong, 3), "frames_rank0": strong["frames"],
+                "source_threads_per_rank": src_threads, "host_ms_per_frame_rank0": strong["host_ms_per_frame"],
+                "note": "same total job at every N: value(N) / value(1) is the strong-scaling speed-up"}
         if hbm_layers is not None:
             line["hbm_bound_layers"] = hbm_layers
         if batched is not None:
             line["batched"] = batched
-        if not args.no_cpu_baseline:
-            # the oracle pass gives both the timed CPU baseline (reported at N = 1, as the contract says) and the
-            # reference labels of the accuracy half of the metric (every N; the other ranks wait at the final barrier)
-            base, base_mm, checked = oracle_pass(model, world=world)
+        if other is not None:
+            line["other_configs"] = other
+        if engine is not None:
+            line["engine"] = engine
+        if checked is not None:
             _log("accuracy: GPU path vs oracle labels on " + checked["what"])
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
             line["accuracy"] = accuracy_block(model, device, checked)
             if world == 1:
                 line["cpu_baseline"] = base

@@ -13,6 +13,7 @@ the Kabsch / averaging solves run through libsvhip.  Differences that are delibe
     reference_key_points moved by the predicted EE pose — the same quantity the reference compares against.
   * predict_translation with q=None: the reference reads an unbound `rot_mat` (F8d); here it raises ValueError.
 """
+import collections
 import os
 
 import numpy as np
@@ -119,24 +120,47 @@ class InferenceEngine:
         R, t = get_rigid_transform_3D(self.reference_key_points[np.asarray(kp_classes)], np.asarray(kp_coords))
         return np.concatenate((t, get_q_from_matrix(R)))
 
+    def _largest_ee_cluster_rule(self, label, xyz):
+        """app/inference_engine.py:419-433 on the device: every EE prediction becomes arm, except the members of the
+        largest single-linkage cluster among them.  label: int64 CUDA [N]; xyz: CUDA [N, 3] (float32, as the reference
+        clusters `seg_points`, the float32 copy of the raw points, :403)."""
+        ee_idx = out_utils.select_equal(label, 2)
+        if ee_idx.numel() > 1:
+            inside = self.cluster_util.get_largest_cluster(xyz, idx=ee_idx)
+            label[ee_idx] = 1
+            label[ee_idx[inside]] = 2
+        elif ee_idx.numel() == 1:
+            label[ee_idx] = 1
+        return label
+
+    def _segment(self, x, field):
+        return self._segmentation_model(x).slice_argmax(field, with_conf=False)[0]
+
     def predict_segmentation(self, points, rgb):
         cfg = self._config
         # F8a: the reference centres the points and then voxelises the RAW ones (:396-408)
         with torch.no_grad():
             field = self._field(points, rgb, cfg.INFERENCE.SEGMENTATION.scale)
-            out = self._segmentation_model(field.sparse())
-            label, _ = out.slice_argmax(field, with_conf=False)
-            # :419-433 on the device: EE predictions -> arm, except the largest single-linkage cluster among them
-            ee_idx = out_utils.select_equal(label, 2)
-            if ee_idx.numel() > 1:
-                pts = np.asarray(points)
-                xyz = torch.as_tensor(pts if pts.dtype in (np.float32, np.float64) else pts.astype(np.float64)).to(self.device)
-                inside = self.cluster_util.get_largest_cluster(xyz, idx=ee_idx)
-                label[ee_idx] = 1
-                label[ee_idx[inside]] = 2
-            elif ee_idx.numel() == 1:
-                label[ee_idx] = 1
+            label = self._segment(field.sparse(), field)
+            xyz = torch.as_tensor(np.asarray(points), dtype=torch.float32).to(self.device)
+            label = self._largest_ee_cluster_rule(label, xyz)
         return label.cpu().numpy()
+
+    def predict_segmentation_stream(self, frames, compute_streams=3):
+        """Streaming form of predict_segmentation for a sequence of frames (the reference's consumer is the per-frame
+        loop of app/main.py:432-456): `frames` yields (points, rgb) host arrays, the generator yields the label arrays in
+        order, each IDENTICAL to predict_segmentation(points, rgb) - while frame i's network runs, frame i+1 is staged
+        through pinned memory, uploaded and voxelised, and frame i-1's cluster rule and label download complete
+        (app/pipeline.py HostFrameStream).  Engine-path throughput: see bench.py's `engine` block."""
+        from .pipeline import HostFrameStream
+
+        # one stream object per configuration, kept: its pinned staging buffers and HIP streams are expensive to create
+        key = (compute_streams, self._config.INFERENCE.SEGMENTATION.scale)
+        streams = self.__dict__.setdefault("_seg_streams", {})
+        if key not in streams:
+            streams[key] = HostFrameStream(self.device, key[1], self._segment, self._largest_ee_cluster_rule,
+                                           compute_streams=compute_streams)
+        return streams[key].run(frames)
 
     def predict_rotation(self, ee_raw_points, ee_rgb):
         cfg = self._config
@@ -217,11 +241,34 @@ class InferenceEngine:
         return True
 
     def predict(self, data: PointCloudDTO):
-        cfg = self._config
         if not self.pred_enabled:
             return ResultDTO(segmentation=np.zeros(len(data.points), dtype=np.int64))
         rgb = preprocess.normalize_colors(data.rgb)
-        seg = self.predict_segmentation(data.points, rgb)
+        return self._predict_after_segmentation(data, rgb, self.predict_segmentation(data.points, rgb))
+
+    def predict_stream(self, frames, compute_streams=3):
+        """predict() over a sequence of PointCloudDTOs with the segmentation stage pipelined across frames
+        (predict_segmentation_stream); the pose stages of a frame (end-effector crop: a few thousand points) run when its
+        labels arrive, while the following frames' segmentation networks are already on the GPU.  Yields the same
+        ResultDTOs, in order, as calling predict() frame by frame."""
+        if not self.pred_enabled:
+            for data in frames:
+                yield ResultDTO(segmentation=np.zeros(len(data.points), dtype=np.int64))
+            return
+        window = collections.deque()
+
+        def inputs():
+            for data in frames:
+                rgb = preprocess.normalize_colors(data.rgb)
+                window.append((data, rgb))
+                yield data.points, rgb
+
+        for seg in self.predict_segmentation_stream(inputs(), compute_streams=compute_streams):
+            data, rgb = window.popleft()
+            yield self._predict_after_segmentation(data, rgb, seg)
+
+    def _predict_after_segmentation(self, data, rgb, seg):
+        cfg = self._config
         result = ResultDTO(segmentation=seg)
         ee_idx = np.where(seg == 2)[0]
         if len(ee_idx) < cfg.INFERENCE.ee_point_counts_threshold:

@@ -10,19 +10,20 @@ recycle their memory under a running kernel.
 """
 import collections
 import os
+import time
 
 import torch
-
-from .. import profiling
 
 from .. import MinkowskiEngine as ME
 
 
 class PreparedFrame:
-    __slots__ = ("field", "x", "ready", "done", "tag")
+    __slots__ = ("field", "x", "ready", "done", "tag", "stream", "result")
 
     def __init__(self, field, x, ready, tag=None):
         self.field, self.x, self.ready, self.done, self.tag = field, x, ready, None, tag
+        self.stream = None  # compute stream run() put the frame on
+        self.result = None
 
 
 def build_unet_plans(cm, levels=4):
@@ -38,7 +39,7 @@ def build_unet_plans(cm, levels=4):
 
 
 class FramePipeline:
-    def __init__(self, device, levels=4, encoder_only=False, compute_streams=1):
+    def __init__(self, device, levels=4, encoder_only=False, compute_streams=1, stagger_level0=None):
         self.device = torch.device(device)
         self.levels = levels
         self.encoder_only = encoder_only
@@ -56,7 +57,7 @@ class FramePipeline:
         # streams: 61.7 frames/s against 62.1 without, but the level-0 launches then run at a steady 0.61 of the matrix
         # peak each instead of 0.48-0.61 depending on how the two frames happen to be phased; three / four / five
         # streams: 64.2 / 63.4 / 63.8 frames/s (63.9-64.5 without at three) at 0.50 / 0.58 / 0.55 per launch.
-        self.stagger_level0 = os.environ.get("MRCC_STAGGER_LEVEL0", "1") == "1"
+        self.stagger_level0 = os.environ.get("MRCC_STAGGER_LEVEL0", "1") == "1" if stagger_level0 is None else bool(stagger_level0)
         self._level0_done = None
         self.single = False  # True: run every frame on the first compute stream (isolated kernel timing)
         self._retired = collections.deque()
@@ -90,15 +91,16 @@ class FramePipeline:
         else:
             compute = torch.cuda.current_stream(self.device)
         compute.wait_event(prepared.ready)
+        prepared.stream = compute
+        # the hook travels with the frame (its coordinate manager), not in a module global: two pipelines or threads do not
+        # see each other's hooks, and model code needs no knowledge of this class
+        cm = prepared.x.coordinate_manager
+        cm.phase_hook = self._phase_hook if (self.stagger_level0 and self.compute_streams and not self.single) else None
         with torch.cuda.stream(compute):
-            if self.stagger_level0 and self.compute_streams and not self.single:
-                profiling.PHASE_HOOK = self._phase_hook
-                try:
-                    out = fn(prepared.x, prepared.field)
-                finally:
-                    profiling.PHASE_HOOK = None
-            else:
+            try:
                 out = fn(prepared.x, prepared.field)
+            finally:
+                cm.phase_hook = None
         prepared.done = torch.cuda.Event()
         prepared.done.record(compute)
         self._retired.append(prepared)
@@ -122,3 +124,125 @@ class FramePipeline:
             st.synchronize()
         torch.cuda.current_stream(self.device).synchronize()
         self._retired.clear()
+
+
+class _HostSlot:
+    """pinned staging buffers of one in-flight frame (host -> device inputs, device -> host labels)"""
+
+    def __init__(self):
+        self.cap = 0
+        self.pts = self.rgb = self.labels = None
+        self.uploaded = None  # event: the slot's H2D copies have finished (safe to refill)
+
+    def reserve(self, n, channels):
+        if n > self.cap or self.rgb.shape[1] != channels:
+            self.cap = max(n, int(self.cap * 1.25))
+            self.pts = torch.empty((self.cap, 3), dtype=torch.float32).pin_memory()
+            self.rgb = torch.empty((self.cap, channels), dtype=torch.float32).pin_memory()
+            self.labels = torch.empty(self.cap, dtype=torch.int64).pin_memory()
+
+
+class HostFrameStream:
+    """Host arrays in -> per-point labels out, frames overlapped (the reference's consumer is a per-frame loop over
+    `InferenceEngine.predict(data)`, app/main.py:432-456; one synchronous frame at a time leaves the GPU idle during
+    staging, H2D, the coordinate read-backs and D2H: 33 ms per 200k-point frame against 16 ms of kernels).
+
+    Per frame: points / colours are copied into PINNED host buffers and uploaded asynchronously on the prep stream, the
+    scaled (batch, x, y, z) rows are formed on the device (`points * scale` in float32 - the same IEEE product the
+    reference computes on the host, app/inference_engine.py:405-409), FramePipeline.prepare() builds the coordinate
+    maps / plans there, `stage(x, field)` (the network + slice/argmax) runs on the next compute stream, and `finish`
+    (whatever needs host decisions: the largest-cluster rule with its count read-back) plus the D2H copy of the labels
+    into pinned memory run on that frame's stream while LATER frames compute.  Results come back in input order and are
+    bit-identical to the synchronous path: the same kernels run on the same data, only their interleaving changes."""
+
+    def __init__(self, device, scale, stage, finish=None, levels=4, compute_streams=3, depth=None, stagger_level0=None):
+        self.device = torch.device(device)
+        self.scale = scale
+        self.stage, self.finish = stage, finish
+        self.pipe = FramePipeline(self.device, levels=levels, compute_streams=compute_streams, stagger_level0=stagger_level0)
+        self.depth = depth or max(2, compute_streams)
+        self._slots = [_HostSlot() for _ in range(self.depth + 2)]
+        self._n = 0
+        # host wall time per phase, summed over frames (perf_counter deltas; tools/engine_stream_phases.py prints them)
+        self.host_s = {"stage": 0.0, "prepare": 0.0, "launch": 0.0, "finalize": 0.0, "frames": 0}
+
+    def _upload_and_prepare(self, points, rgb):
+        import numpy as np
+
+        t0 = time.perf_counter()
+        slot = self._slots[self._n % len(self._slots)]
+        self._n += 1
+        if slot.uploaded is not None:
+            slot.uploaded.synchronize()
+        n = len(points)
+        rgb_t = rgb if torch.is_tensor(rgb) else None
+        channels = (rgb_t.shape[1] if rgb_t is not None else np.asarray(rgb).shape[1])
+        slot.reserve(n, channels)
+        np.copyto(slot.pts.numpy()[:n], np.asarray(points), casting="same_kind")  # float64 sources are rounded here
+        if rgb_t is not None:
+            slot.rgb[:n].copy_(rgb_t)
+        else:
+            np.copyto(slot.rgb.numpy()[:n], np.asarray(rgb), casting="same_kind")
+        prep = self.pipe.prep_stream
+        t1 = time.perf_counter()
+        with torch.cuda.stream(prep):
+            d_pts = slot.pts[:n].to(self.device, non_blocking=True)
+            d_rgb = slot.rgb[:n].to(self.device, non_blocking=True)
+            slot.uploaded = torch.cuda.Event()
+            slot.uploaded.record(prep)
+            coords4 = torch.zeros((n, 4), dtype=torch.float32, device=self.device)
+            torch.mul(d_pts, self.scale, out=coords4[:, 1:])
+        out = self.pipe.prepare(coords4, d_rgb, tag=(slot, d_pts, n))
+        t2 = time.perf_counter()
+        self.host_s["stage"] += t1 - t0
+        self.host_s["prepare"] += t2 - t1
+        self.host_s["frames"] += 1
+        return out
+
+    def _launch(self, prepared):
+        t0 = time.perf_counter()
+        prepared.result = self.pipe.run(prepared, self.stage)
+        self.host_s["launch"] += time.perf_counter() - t0
+
+    def _finalize(self, prepared):
+        import numpy as np
+
+        t0 = time.perf_counter()
+        slot, d_pts, n = prepared.tag
+        stream = prepared.stream if prepared.stream is not None else torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(stream):
+            label = prepared.result
+            if self.finish is not None:
+                label = self.finish(label, d_pts)
+            slot.labels[:n].copy_(label, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(stream)
+        done.synchronize()
+        out = np.array(slot.labels.numpy()[:n])  # leave the pinned buffer free for the next frame
+        prepared.result = prepared.tag = None
+        self.host_s["finalize"] += time.perf_counter() - t0
+        return out
+
+    def run(self, frames):
+        """frames: iterable of (points [N,3], rgb [N,C]) host arrays -> generator of int64 label arrays, in order."""
+        pending = collections.deque()
+        it = iter(frames)
+        try:
+            first = next(it)
+        except StopIteration:
+            return
+        with torch.no_grad():
+            nxt = self._upload_and_prepare(*first)
+            while nxt is not None:
+                cur = nxt
+                self._launch(cur)  # asynchronous: the GPU works on `cur` while the host stages the next frame
+                pending.append(cur)
+                try:
+                    nxt = self._upload_and_prepare(*next(it))
+                except StopIteration:
+                    nxt = None
+                while len(pending) >= self.depth:
+                    yield self._finalize(pending.popleft())
+            while pending:
+                yield self._finalize(pending.popleft())
+            self.pipe.drain()

@@ -108,6 +108,12 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
 // Stage 1: every workgroup reduces a contiguous slab of rows to one record; stage 2: one workgroup reduces the records
 // in slab order (deterministic: no atomics).
 constexpr int STAT_REC = 16;  // doubles per record: min[4], max[4], sum[4], normmax, pad
+// numpy's min() / max() propagate NaN (fminf / fmaxf drop it): a NaN colour or point must steer the data-dependent
+// branches of utils/preprocess.py:20-37 on the device exactly as on the host
+__device__ __forceinline__ float nan_min(float a, float b) { return (a != a) ? a : ((b != b) ? b : fminf(a, b)); }
+__device__ __forceinline__ float nan_max(float a, float b) { return (a != a) ? a : ((b != b) ? b : fmaxf(a, b)); }
+__device__ __forceinline__ double nan_min(double a, double b) { return (a != a) ? a : ((b != b) ? b : fmin(a, b)); }
+__device__ __forceinline__ double nan_max(double a, double b) { return (a != a) ? a : ((b != b) ? b : fmax(a, b)); }
 __global__ __launch_bounds__(256) void col_stats_partial_kernel(const float* __restrict__ x, int64_t ld, int64_t N, int C,
                                                                  const float* __restrict__ sub, int64_t rows_per_block,
                                                                  double* __restrict__ rec) {
@@ -126,23 +132,23 @@ __global__ __launch_bounds__(256) void col_stats_partial_kernel(const float* __r
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     for (int c = 0; c < C; ++c) {
       v[c] = x[r * ld + c];
-      mn[c] = fminf(mn[c], v[c]);
-      mx[c] = fmaxf(mx[c], v[c]);
+      mn[c] = nan_min(mn[c], v[c]);
+      mx[c] = nan_max(mx[c], v[c]);
       sm[c] += (double)v[c];
     }
     if (sub) {
       const float a = v[0] - sub[0], b = v[1] - sub[1], d = (C > 2) ? v[2] - sub[2] : 0.0f;
-      nmax = fmaxf(nmax, sqrtf((a * a + b * b) + d * d));
+      nmax = nan_max(nmax, sqrtf((a * a + b * b) + d * d));
     }
   }
   // wave reduction by shuffles, then across the four waves through LDS
   for (int off = 32; off >= 1; off >>= 1) {
     for (int c = 0; c < 4; ++c) {
-      mn[c] = fminf(mn[c], __shfl_down(mn[c], off));
-      mx[c] = fmaxf(mx[c], __shfl_down(mx[c], off));
+      mn[c] = nan_min(mn[c], __shfl_down(mn[c], off));
+      mx[c] = nan_max(mx[c], __shfl_down(mx[c], off));
       sm[c] += __shfl_down(sm[c], off);
     }
-    nmax = fmaxf(nmax, __shfl_down(nmax, off));
+    nmax = nan_max(nmax, __shfl_down(nmax, off));
   }
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (lane == 0) {
@@ -157,7 +163,8 @@ __global__ __launch_bounds__(256) void col_stats_partial_kernel(const float* __r
   if (threadIdx.x < STAT_REC) {
     const int j = threadIdx.x;
     double a = sh[0][j];
-    for (int w = 1; w < 4; ++w) a = (j < 4) ? fmin(a, sh[w][j]) : ((j < 8 || j == 12) ? fmax(a, sh[w][j]) : a + sh[w][j]);
+    for (int w = 1; w < 4; ++w)
+      a = (j < 4) ? nan_min(a, sh[w][j]) : ((j < 8 || j == 12) ? nan_max(a, sh[w][j]) : a + sh[w][j]);
     rec[(int64_t)blockIdx.x * STAT_REC + j] = (j > 12) ? 0.0 : a;
   }
 }
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(64) void col_stats_final_kernel(const double* __res
   double a = rec[j];
   for (int b = 1; b < nrec; ++b) {
     const double v = rec[(int64_t)b * STAT_REC + j];
-    a = (j < 4) ? fmin(a, v) : ((j < 8 || j == 12) ? fmax(a, v) : a + v);
+    a = (j < 4) ? nan_min(a, v) : ((j < 8 || j == 12) ? nan_max(a, v) : a + v);
   }
   if (j < 4 && j < C) mn[j] = (float)a;
   if (j >= 4 && j < 8 && j - 4 < C) mx[j - 4] = (float)a;

@@ -78,11 +78,12 @@ class MinkUNetBase(ResNetBase):
     def forward_except_final(self, x):
         out, skips = self.encode(x)
         n = self.N_LEVELS
-        from ... import profiling
-
+        # optional per-frame callable the frame pipeline attaches to the frame's coordinate manager (app/pipeline.py): it is
+        # told where the stride-1 decoder stage (the chip-filling 63 % of a frame) begins and ends
+        phase_hook = getattr(x.coordinate_manager, "phase_hook", None)
         for j in range(n, 2 * n):
             conv, bn, block = self._up_names(j)
-            hook = profiling.PHASE_HOOK if j == 2 * n - 1 else None
+            hook = phase_hook if j == 2 * n - 1 else None
             if hook is not None:
                 hook("level0_begin")
             # transposed conv + BN + ReLU written straight into the left columns of ME.cat(out, skip)

@@ -12,10 +12,6 @@ TIMER = None  # set by bench.py
 # Optional list: nn.conv_forward appends (instance name, {"fast", "ring", "full"}, K, Cin, Cout, rows) per launch, as
 # reported by the library itself (sv_conv_last_instance) - tests check which instances a configuration really ran on.
 INSTANCE_LOG = None
-# Optional callable(tag) the backbone calls at "level0_begin" / "level0_end" (its stride-1 decoder stage, the chip-filling
-# 63 % of a frame): the frame pipeline uses it to keep the level-0 stages of consecutive frames from overlapping.
-PHASE_HOOK = None
-
 
 _CANDIDATES = {
     "wide3": [(64, 4, 3, 2500), (32, 4, 3, 1500), (32, 2, 3, 0)],

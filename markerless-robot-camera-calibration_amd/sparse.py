@@ -135,6 +135,7 @@ class CoordinateManager:
         self._batch_offsets = {}
         self._batch_bounds = {}
         self.num_batches = None
+        self.phase_hook = None  # set per frame by app/pipeline.py FramePipeline.run (see model/backbone/minkunet.py)
 
     def _own(self, plan, nbr, ld, mask, in_stride, out_stride):
         plan.cm, plan.raw, plan.in_stride, plan.out_stride = self, (nbr, ld, mask), in_stride, out_stride

@@ -84,10 +84,13 @@ def normalize_colors(rgb_input, is_color_in_range_0_255=False):
             x = _apply(x, div=torch.full((x.shape[1],), 255.0, device=dev))
             lo, hi = lo / np.float32(255.0), hi / np.float32(255.0)
         if lo.min() < 0:
+            # utils/preprocess.py:28-30 rescales columns 0..2 only; a fourth column passes through
             rng = hi - lo
             rng[rng == 0] = 1.0
-            x = _apply(x, sub=torch.from_numpy(lo).to(dev), div=torch.from_numpy(rng.astype(np.float32)).to(dev))
-            lo, hi = np.zeros_like(lo), np.ones_like(hi)
+            sub, div = lo.copy(), rng.astype(np.float32)
+            sub[3:], div[3:] = 0.0, 1.0
+            x = _apply(x, sub=torch.from_numpy(sub).to(dev), div=torch.from_numpy(div).to(dev))
+            lo[:3], hi[:3] = 0.0, 1.0
         if lo.min() > (-1e-6) and hi.max() < (1 + 1e-6):
             x = _apply(x, sub=torch.full((x.shape[1],), 0.5, device=dev))
         return x

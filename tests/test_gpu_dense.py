@@ -236,6 +236,20 @@ def test_preprocess_device_path_vs_reference_golden(gpu, golden):
     assert np.array_equal(c1.cpu().numpy(), want_c) and np.array_equal(o1.cpu().numpy(), want_o)
     c2, _ = P.center_at_origin(t(wide)[:, 1:4])
     assert torch.equal(c1, c2)
+    # NaN inputs: numpy's min / max propagate NaN, so must the device statistics - a NaN point gives a NaN offset, and a
+    # NaN colour steers the data-dependent branches of normalize_colors exactly like the host path
+    bad = g["points"].copy()
+    bad[17, 1] = np.nan
+    cb, ob = P.center_at_origin(t(bad))
+    hb, hob = P.center_at_origin(bad)
+    assert np.array_equal(ob.cpu().numpy(), hob, equal_nan=True) and np.isnan(ob.cpu().numpy()[1])
+    assert np.array_equal(cb.cpu().numpy(), hb, equal_nan=True)
+    badc = g["rgb255"].copy()
+    badc[5, 2] = np.nan
+    assert np.array_equal(P.normalize_colors(t(badc)).cpu().numpy(), P.normalize_colors(badc), equal_nan=True)
+    # four columns: only the first three take the min-max branch (utils/preprocess.py:28-30)
+    neg4 = rng.uniform(-0.3, 0.9, size=(3000, 4)).astype(np.float32)
+    assert np.allclose(P.normalize_colors(t(neg4)).cpu().numpy(), P.normalize_colors(neg4), atol=2e-7, rtol=0)
 
 
 @pytest.mark.parametrize("B,N,S,C", [(2, 500, 64, 38), (1, 2048, 1024, 256), (3, 70, 3, 5), (1, 64, 300, 1)])
