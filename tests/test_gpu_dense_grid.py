@@ -50,8 +50,17 @@ class DenseNet:
     def up(self, x, name, level):  # transposed kernel 2 stride 2 onto the EXISTING map of level - 1
         return F.conv_transpose3d(x, _dense_weights3(self.sd[name + ".kernel"], True), stride=2) * self.masks[level - 1]
 
-    def block(self, x, name, level):  # BasicBlock
+    def block(self, x, name, level):
         m = self.masks[level]
+        if name + ".conv3.kernel" in self.sd:  # Bottleneck (resnet_block.Bottleneck): 1x1 - 3x3 - 1x1, expansion 4
+            out = F.relu(self.bn(self.conv(x, name + ".conv1", level), name + ".norm1")) * m
+            out = F.relu(self.bn(self.conv(out, name + ".conv2", level), name + ".norm2")) * m
+            out = self.bn(self.conv(out, name + ".conv3", level), name + ".norm3") * m
+            res = x
+            if name + ".downsample.0.kernel" in self.sd:
+                res = self.bn(self.conv(x, name + ".downsample.0", level), name + ".downsample.1") * m
+            return F.relu(out + res) * m
+        # BasicBlock
         out = F.relu(self.bn(self.conv(x, name + ".conv1", level), name + ".norm1")) * m
         out = self.bn(self.conv(out, name + ".conv2", level), name + ".norm2") * m
         res = x
@@ -81,7 +90,15 @@ class DenseNet:
             out = torch.cat([out, skips.pop()], dim=1)
             out = self.stack(out, f"block{j + 1}", level - 1)
         w, b = self.sd["final.kernel"].double(), self.sd["final.bias"].double().view(1, -1, 1, 1, 1)
-        return (F.conv3d(out, w.t().reshape(w.shape[1], w.shape[0], 1, 1, 1)) + b) * m[0]
+        out = (F.conv3d(out, w.t().reshape(w.shape[1], w.shape[0], 1, 1, 1)) + b) * m[0]
+        if "regression.0.linear.weight" not in self.sd:
+            return out
+        # classification head (model/robotnet_segmentation.py:55-64): LeakyReLU -> Linear 256->1024 -> LeakyReLU -> Linear
+        lin = lambda t, n: F.conv3d(t, self.sd[f"regression.{n}.linear.weight"].double()[:, :, None, None, None],
+                                    self.sd[f"regression.{n}.linear.bias"].double())
+        out = F.leaky_relu(out, 0.01)
+        out = F.leaky_relu(lin(out, 0), 0.01)
+        return lin(out, 2) * m[0]
 
 
 def _cloud(seed, n):
@@ -96,12 +113,32 @@ def _cloud(seed, n):
     return c[rng.permutation(len(c))]
 
 
-def test_minkunet14a_matches_dense_grid_float64(gpu):
+def _nets():
+    from mrcc_amd.MinkowskiEngine.modules.resnet_block import Bottleneck
+    from mrcc_amd.model.backbone.minkunet import MinkUNet14A, MinkUNetBase
+    from mrcc_amd.model.robotnet_segmentation import _classification_head
+
+    class BottleneckUNet(MinkUNetBase):
+        """the MinkUNet50 / 101 graph (Bottleneck blocks, expansion 4: 1x1 downsample-with-concat widths, 1x1 - 3x3 - 1x1
+        stacks) at widths a float64 dense grid can afford"""
+        BLOCK = Bottleneck
+        LAYERS = (1, 2, 1, 1, 1, 1, 2, 1)
+        PLANES = (8, 16, 16, 32, 32, 16, 8, 8)
+        INIT_DIM = 16
+
+    return {"minkunet14a": lambda: MinkUNet14A(3, 20),
+            "bottleneck_unet": lambda: BottleneckUNet(3, 20),
+            # the segmentation head's dense layers (256 -> 1024 -> classes) behind a BasicBlock U-Net
+            "seg_head": lambda: _classification_head(MinkUNet14A, lambda: 3, "SegHead14A")(3, num_classes=3)}
+
+
+@pytest.mark.parametrize("which", ["minkunet14a", "bottleneck_unet", "seg_head"])
+def test_unet_matches_dense_grid_float64(gpu, which):
     from mrcc_amd import MinkowskiEngine as ME
-    from mrcc_amd.model.backbone.minkunet import MinkUNet14A
 
     torch.manual_seed(21)
-    net = MinkUNet14A(3, 20)
+    net = _nets()[which]()
+    n_out = 3 if which == "seg_head" else 20
     g = torch.Generator().manual_seed(22)
     with torch.no_grad():
         for mod in net.modules():
@@ -136,7 +173,7 @@ def test_minkunet14a_matches_dense_grid_float64(gpu):
     torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
     want_dense = DenseNet(net.state_dict(), masks).forward(dense)
     want = want_dense[oc[:, 0], :, oc[:, 3] + OFF, oc[:, 2] + OFF, oc[:, 1] + OFF].numpy()
-    assert got.shape == want.shape == (sum(len(c) for c in clouds), 20)
+    assert got.shape == want.shape == (sum(len(c) for c in clouds), n_out)
     scale = np.abs(want).max()
     err = np.abs(got - want).max()
     assert scale > 0.05 and err < 1e-4 * max(1.0, scale), (err, scale)
