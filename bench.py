@@ -340,51 +340,87 @@ def accuracy_block(model, device, checked):
 
 
 def hbm_bound_layers(model, device, iters=60):
-    """The gather-bound layers of the network, each timed as `iters` back-to-back launches on the seed-0 frame (HIP
-    events on the launch stream): achieved GB/s = SURVEY.md 8(d) algorithmic gather-bytes / time, against the 8 TB/s HBM
-    peak.  north_star target: >= 40 % on the sparse-conv gather at 80k active voxels.  (In the frame these launches are
-    16-110 us long; inside the pipelined timed region the first launch of a frame - conv0 - sits behind a cross-stream
-    wait, so it is measured here, where nothing else runs.)"""
+    """The gather-bound layers of the network, each timed as `iters` back-to-back launches (HIP events on the launch stream):
+    achieved GB/s = SURVEY.md 8(d) algorithmic gather-bytes / time, against the 8 TB/s HBM peak.  north_star target:
+    >= 40 % on the sparse-conv gather at 80k active voxels.  Two ways of issuing the series: `us_per_launch` = a hipGraph
+    replay of the series (device-side back-to-back: what the kernels cost the GPU) and `us_per_launch_eager` = one host call
+    per launch (a one-row launch issued that way already takes `eager_launch_floor_us`: the host's issue rate).  Each layer
+    on the seed-0 frame (88k / 26k voxels) and on four frames in one tensor (352k / 106k voxels): at frame size the
+    launches are one round of waves whose duration is a single wave's chain of dependent round trips, not bytes
+    (profiles/r03_launch_floor.txt: the same kernels on a 16th of the frame take as long)."""
     from mrcc_amd import nn as svnn
 
-    frame = make_frame(0, device)
     out = {}
+
+    def series(fn):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        eager = e0.elapsed_time(e1) / iters * 1e3
+        graph_us = None
+        try:
+            st = torch.cuda.Stream(device=device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(st):
+                with torch.cuda.graph(g, stream=st):
+                    for _ in range(iters):
+                        fn()
+                g.replay()
+                st.synchronize()
+                e0.record(st)
+                g.replay()
+                e1.record(st)
+                st.synchronize()
+            graph_us = e0.elapsed_time(e1) / iters * 1e3
+        except Exception as exc:  # capture is an optimisation of the measurement, never a requirement
+            _log(f"hbm_bound_layers: graph capture unavailable ({type(exc).__name__}); eager series only")
+        return eager, graph_us
+
     with torch.no_grad():
-        field = ME.TensorField(frame[1], frame[0], quantization_mode=ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE,
-                               device=device)
-        x = field.sparse()
-        cm = x.coordinate_manager
-        V0, V1 = cm.stride_map(1).V, cm.stride_map(2).V
-        p0, p1 = cm.plan_k3(1), cm.plan_k3(2)
-        blk = model.block1[0]
-        s0, b0 = model.bn0.folded()
-        s1, b1 = blk.norm1.folded()
-        f1 = torch.randn(V1, 32, device=device)
-        f1024 = torch.randn(V0, 1024, device=device)
-        head = model.regression[2]
-        cases = {
-            "conv0 3->32 k27 (level 0)": (x.F, model.conv0p1s1.weight3().detach(), p0, V0, s0, b0),
-            "block1 32->32 k27 (level 1)": (f1, blk.conv1.weight3().detach(), p1, V1, s1, b1),
-            "regression.2 1024->3 (level 0)": (f1024, head.weight3(), None, V0, None, head.linear.bias.detach()),
-        }
-        for name, (f, w, plan, V, sc, sh) in cases.items():
-            K, Cin, Cout = w.shape
-            for _ in range(3):
-                svnn.conv_forward(f, w, plan, V, sc, sh, None, 1)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(iters):
-                svnn.conv_forward(f, w, plan, V, sc, sh, None, 1)
-            e1.record()
-            torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) / iters * 1e3
-            P = plan.num_pairs() if plan is not None else V
-            gb = (P * (4.0 * Cin + 8) + 4.0 * V * Cout + 4.0 * K * Cin * Cout) / 1e9
-            Vpad = plan.Vpad if plan is not None else (V + 127) // 128 * 128
-            out[name] = {"kernel": profiling.conv_kernel_config(Cout, Vpad, Cin, K), "rows": int(V), "us_per_launch": round(us, 2),
-                         "algorithmic_MB": round(gb * 1e3, 2), "GBps": round(gb / (us * 1e-6), 1),
-                         "frac_of_hbm_peak": round(gb / (us * 1e-6) / PEAK_HBM_GBS, 4)}
+        tiny = torch.zeros(1, 32, device=device)
+        tiny_out = torch.empty_like(tiny)
+        w1 = torch.zeros(1, 32, 32, device=device)
+        floor, floor_graph = series(lambda: svnn.conv_forward(tiny, w1, None, 1, out=tiny_out))
+        out["eager_launch_floor_us"] = round(floor, 2)
+        out["graph_launch_floor_us"] = None if floor_graph is None else round(floor_graph, 2)
+        for batch, tag in ((1, ""), (4, " x4 frames")):
+            frame = make_frame(0, device, batch=batch)
+            field = ME.TensorField(frame[1], frame[0], quantization_mode=ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE,
+                                   device=device)
+            x = field.sparse()
+            cm = x.coordinate_manager
+            V0, V1 = cm.stride_map(1).V, cm.stride_map(2).V
+            p0, p1 = cm.plan_k3(1), cm.plan_k3(2)
+            blk = model.block1[0]
+            s0, b0 = model.bn0.folded()
+            s1, b1 = blk.norm1.folded()
+            f1 = torch.randn(V1, 32, device=device)
+            f1024 = torch.randn(V0, 1024, device=device)
+            head = model.regression[2]
+            cases = {
+                "conv0 3->32 k27 (level 0)": (x.F, model.conv0p1s1.weight3().detach(), p0, V0, s0, b0),
+                "block1 32->32 k27 (level 1)": (f1, blk.conv1.weight3().detach(), p1, V1, s1, b1),
+                "regression.2 1024->3 (level 0)": (f1024, head.weight3(), None, V0, None, head.linear.bias.detach()),
+            }
+            for name, (f, w, plan, V, sc, sh) in cases.items():
+                K, Cin, Cout = w.shape
+                dst = torch.empty(V, Cout, device=device)
+                eager, graph_us = series(lambda: svnn.conv_forward(f, w, plan, V, sc, sh, None, 1, out=dst))
+                us = graph_us if graph_us is not None else eager
+                P = plan.num_pairs() if plan is not None else V
+                gb = (P * (4.0 * Cin + 8) + 4.0 * V * Cout + 4.0 * K * Cin * Cout) / 1e9
+                out[name + tag] = {"kernel": mrcc_amd._lib.conv_last_instance()[0], "rows": int(V),
+                                   "us_per_launch": round(us, 2), "us_per_launch_eager": round(eager, 2),
+                                   "timing": "hipGraph replay" if graph_us is not None else "eager series",
+                                   "algorithmic_MB": round(gb * 1e3, 2), "GBps": round(gb / (us * 1e-6), 1),
+                                   "frac_of_hbm_peak": round(gb / (us * 1e-6) / PEAK_HBM_GBS, 4)}
+            del frame, field, x, f1, f1024
     return out
 
 

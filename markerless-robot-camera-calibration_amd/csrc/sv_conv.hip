@@ -157,20 +157,10 @@ struct ConvCfg {
 // ---- epilogue of the buffer-addressed kernels: BN(eval) / bias -> residual -> activation -> store by `perm`.
 //      acc[s][n][reg]: C/D map of the matrix op, column = lane & 15 of column tile n (output channel col0 + n), row =
 //      rows0 + 16 s + 4 lq + reg of the plan.
-template <int MR, int NT>
-__device__ __forceinline__ void epilogue_buffered(const ConvParams& p, const f32x4 (&acc)[MR][NT], const int64_t rows0,
-                                                  const int lq, const int col0) {
-  // branch-free: the 4 consecutive output rows a lane holds per sub-tile come from ONE int4 load of `perm`, all MR of
-  // them requested up front; a sub-tile's residual rows are requested together; rows past V_out (perm < 0) get a
-  // byte offset beyond the extents, so their residual loads return zeros and their stores are dropped by the
-  // descriptor's range check.  (With a branch per row and per column the epilogue was a chain of dependent round
-  // trips - 31 us of a 770 us workgroup on the 64-row tile; this form: dense layers +4-5 %, the level-0 launch and
-  // the frame rate +1.2 %.)
-  typedef float yvec_t __attribute__((ext_vector_type(NT)));
-  const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)p.out_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_res =
-      __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, p.residual ? (int)p.res_bytes : 0, 0x00020000);
-  int o[MR][4];
+// the 4 consecutive plan rows a lane stores per sub-tile (one int4 of `perm`); the single-wave kernels request them at
+// their very start so that the epilogue does not begin with a dependent round trip
+template <int MR>
+__device__ __forceinline__ void load_perm_rows(const ConvParams& p, const int64_t rows0, const int lq, int (&o)[MR][4]) {
 #pragma unroll
   for (int s = 0; s < MR; ++s) {
     const int64_t r = rows0 + s * 16 + lq * 4;
@@ -184,6 +174,30 @@ __device__ __forceinline__ void epilogue_buffered(const ConvParams& p, const f32
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) o[s][reg] = (r + reg < p.V_out) ? (int)(r + reg) : -1;
     }
+  }
+}
+
+template <int MR, int NT, bool PRELOADED = false>
+__device__ __forceinline__ void epilogue_buffered(const ConvParams& p, const f32x4 (&acc)[MR][NT], const int64_t rows0,
+                                                  const int lq, const int col0, const int (*o_pre)[4] = nullptr) {
+  // branch-free: the 4 consecutive output rows a lane holds per sub-tile come from ONE int4 load of `perm`, all MR of
+  // them requested up front; a sub-tile's residual rows are requested together; rows past V_out (perm < 0) get a
+  // byte offset beyond the extents, so their residual loads return zeros and their stores are dropped by the
+  // descriptor's range check.  (With a branch per row and per column the epilogue was a chain of dependent round
+  // trips - 31 us of a 770 us workgroup on the 64-row tile; this form: dense layers +4-5 %, the level-0 launch and
+  // the frame rate +1.2 %.)
+  typedef float yvec_t __attribute__((ext_vector_type(NT)));
+  const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)p.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_res =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, p.residual ? (int)p.res_bytes : 0, 0x00020000);
+  int o[MR][4];
+  if constexpr (PRELOADED) {
+#pragma unroll
+    for (int s = 0; s < MR; ++s)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) o[s][reg] = o_pre[s][reg];
+  } else {
+    load_perm_rows<MR>(p, rows0, lq, o);
   }
   // The arithmetic is unconditional: absent BN / bias / residual become operands that change no bit of any value
   // (fmaf(x, 1, -0) == x and x + (-0) == x for every x, signed zeros and NaN included; bias alone: fmaf(x, 1, b) is
@@ -843,9 +857,13 @@ __device__ __forceinline__ void transpose4x4_lanegroups(float& r0, float& r1, fl
   r3 = __uint_as_float(d.y);
 }
 
-template <int CIN, int COUT, int MR, int D>
+template <int CIN, int COUT, int MR, int D, int CSPLIT = 1>
 __global__ __launch_bounds__(256) void conv_thin_kernel(ConvParams p) {
-  constexpr int NT = COUT / 16;  // MFMA column tiles per wave; interleaved: column li of tile n = channel NT * li + n
+  // CSPLIT > 1: blockIdx.y selects a slice of COUT / CSPLIT output channels (the gathers are repeated per slice - they hit
+  // the L2 - but a wave's matrix work and weight registers shrink by CSPLIT and the launch has CSPLIT times the waves: on
+  // the small pyramid levels a launch is a few waves per SIMD, bound by one wave's chain of offsets)
+  constexpr int NT = COUT / 16 / CSPLIT;  // MFMA column tiles per wave; interleaved: column li of tile n = channel NT * li + n
+  const int cbase = (int)blockIdx.y * (COUT / CSPLIT);
   constexpr int KS = CIN / 4;    // k-steps per offset
   constexpr int G4 = CIN / 16;   // float4 gathers per lane, row and offset
   // MR: 16-row sub-tiles per wave (they share every weight register: half the weight traffic per row at MR = 2);
@@ -865,6 +883,8 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvParams p) {
   const int64_t t128 = row0 / PLAN_TILE;
   const int sub = (int)((row0 % PLAN_TILE) / 16);
   // ---- active offsets of this wave's sub-tile(s), compacted; neighbour rows of its rows for every offset
+  int o_pre[MR][4];
+  load_perm_rows<MR>(p, row0, lq, o_pre);
   const bool active = lane < K && ((p.submask[t128 * K + lane] >> sub) & ((1u << MR) - 1u));
   const unsigned long long amask = __ballot(active);
   const int nact = __popcll(amask);
@@ -920,7 +940,7 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvParams p) {
     const uint32_t wk = (uint32_t)offset_of(j) * (uint32_t)(CIN * COUT * 4);  // wave-uniform: the SGPR offset
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
-      dst[ks] = buffer_load_floats<NT>(rsrc_w, (uint32_t)(lq * COUT + NT * li) * 4u, wk + (uint32_t)(4 * ks * COUT * 4));
+      dst[ks] = buffer_load_floats<NT>(rsrc_w, (uint32_t)(lq * COUT + cbase + NT * li) * 4u, wk + (uint32_t)(4 * ks * COUT * 4));
   };
   auto compute = [&](float4 (&a)[MR][G4], bvec_t (&w)[KS]) {
 #pragma unroll
@@ -956,14 +976,94 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvParams p) {
     }
   }
   // ---- epilogue (shared with conv_tile_body): C/D map: MFMA col = lane & 15, row = (lane >> 4) * 4 + reg
-  epilogue_buffered<MR, NT>(p, acc, row0, lq, NT * li);
+  epilogue_buffered<MR, NT, true>(p, acc, row0, lq, cbase + NT * li, o_pre);
+}
+
+// ---- first layer on the matrix pipe (conv0: 3 -> 32, every voxel of the frame; model/backbone/minkunet.py:55-57).
+//      The 27 x 3 = 81 (offset, channel) products of an output element are ONE ascending chain, so the layer is a
+//      [V x 81] x [81 x 32] product whose A rows are gathered: 21 k-steps of 4 (the last three columns read zeros).  One
+//      wave owns a 16-row sub-tile and never synchronises with anybody: lane (row li, group lq) fetches element
+//      e = 4 ks + lq of its row - channel e % 3 of the neighbour at offset e / 3 - for all 21 k-steps at once (21 dword
+//      gathers in flight per lane behind ONE round trip for the wave's neighbour table), the 81 x 32 weights arrive in the
+//      matrix-op layout straight from L2 meanwhile (requested before the table), then 42 matrix ops.  Against the
+//      thread-per-voxel VALU kernel: 5.4 instead of 1.3 waves per SIMD and 1 344 instead of 2 592 issue cycles per 16 rows.
+//      Same chain order (k ascending, c ascending), absent neighbours contribute fma(0, w, acc) = acc.
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_first_mfma_kernel(ConvParams p) {
+  constexpr int CIN = 3, KMAX = 27, E = KMAX * CIN, KS = (E + 3) / 4, NT = COUT / 16;
+  constexpr int SX = 85;  // LDS row stride of the gathered [16 rows][81] block: 85 = 21 mod 32 spreads the rows over the banks
+  constexpr int PAIRS = KMAX * 16, IT = (PAIRS + 63) / 64;
+  typedef float bvec_t __attribute__((ext_vector_type(NT)));
+  __shared__ float xs[4][16 * SX];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, lq = lane >> 4;
+  const int K = p.K;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + wid) * 16;  // Vpad is a multiple of 128: every wave has its rows
+  const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)p.w_bytes, 0x00020000);
+  // weights first: they depend on nothing.  Row e of the flat [K * 3][COUT] weight block; rows past the extent (e >= 3 K)
+  // read zeros through the range check
+  bvec_t b[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+    b[ks] = buffer_load_floats<NT>(rsrc_w, (uint32_t)(lq * COUT + NT * li) * 4u, (uint32_t)(4 * ks * COUT * 4));
+  int o_pre[1][4];
+  load_perm_rows<1>(p, row0, lq, o_pre);
+  // the wave's 27 x 16 (offset, row) pairs, one per lane and pass: consecutive lanes = consecutive rows of one offset, so
+  // the index reads are coalesced, and each pair is ONE 12-byte gather (a third of the requests of per-element gathers:
+  // at four frames per tensor the per-element form was bound by the texture addresser, 0.32 of the HBM peak)
+  int n_st[IT];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int pr = lane + 64 * it;
+    n_st[it] = (pr < K * 16) ? p.nbr_s[(int64_t)(pr >> 4) * p.Vpad + row0 + (pr & 15)] : -1;
+  }
+  typedef float f32x3 __attribute__((ext_vector_type(3)));
+  f32x3 g[IT];
+#pragma unroll
+  for (int it = 0; it < IT; ++it)
+    g[it] = buffer_load_floats<3>(rsrc_in, n_st[it] >= 0 ? (uint32_t)n_st[it] * (uint32_t)(p.in_ld * 4) : BUF_ABSENT, 0u);
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int pr = lane + 64 * it;
+    if (pr < PAIRS) {
+      float* d = &xs[wid][(pr & 15) * SX + 3 * (pr >> 4)];
+      d[0] = g[it][0];
+      d[1] = g[it][1];
+      d[2] = g[it][2];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();  // same-wave LDS traffic is ordered; keep the compiler from moving reads above
+  float a[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int e = 4 * ks + lq;
+    a[ks] = e < E ? xs[wid][li * SX + e] : 0.0f;
+  }
+  f32x4 acc[1][NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) acc[0][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], b[ks][n], acc[0][n], 0, 0, 0);
+  epilogue_buffered<1, NT, true>(p, acc, row0, lq, NT * li, o_pre);
 }
 
 static int launch_conv_thin(const ConvParams& p, hipStream_t stream) {
   // one 16-row sub-tile per wave, four offsets in flight: 24 us for block1's 32->32 at level 1 (26.5k voxels) against 35 us
   // on the LDS-staged fused-offset tile, 49 against 84 us at 88k voxels (2.65 TB/s on algorithmic gather-bytes).  Two
   // sub-tiles per wave (shared weight registers) 27-28 / 48 us, three or six offsets in flight 26 / 51-54 us.
-  hipLaunchKernelGGL((conv_thin_kernel<32, 32, 1, 4>), dim3((unsigned)(p.Vpad / 64)), dim3(256), 0, stream, p);
+  static const int variant = getenv("SV_THIN_VARIANT") ? atoi(getenv("SV_THIN_VARIANT")) : 0;  // experiments only
+  const dim3 g1((unsigned)(p.Vpad / 64)), g2((unsigned)(p.Vpad / 64), 2);
+  switch (variant) {
+    case 1: hipLaunchKernelGGL((conv_thin_kernel<32, 32, 1, 4, 2>), g2, dim3(256), 0, stream, p); break;
+    case 2: hipLaunchKernelGGL((conv_thin_kernel<32, 32, 1, 6, 2>), g2, dim3(256), 0, stream, p); break;
+    case 3: hipLaunchKernelGGL((conv_thin_kernel<32, 32, 1, 8, 2>), g2, dim3(256), 0, stream, p); break;
+    case 4: hipLaunchKernelGGL((conv_thin_kernel<32, 32, 1, 8, 1>), g1, dim3(256), 0, stream, p); break;
+    default: hipLaunchKernelGGL((conv_thin_kernel<32, 32, 1, 4>), g1, dim3(256), 0, stream, p); break;
+  }
   note_instance("conv_thin_kernel<32, 32>|fast=1,ring=0,full=1");
   SV_LAUNCH_CHECK();
   return SV_OK;
@@ -1040,6 +1140,13 @@ __global__ __launch_bounds__(256) void conv_first_layer_kernel(ConvParams p) {
 #pragma unroll
     for (int j = 0; j < CT; ++j) dst[j] = acc[j];
   }
+}
+
+static int launch_conv_first_mfma(const ConvParams& p, hipStream_t stream) {
+  hipLaunchKernelGGL((conv_first_mfma_kernel<32>), dim3((unsigned)(p.Vpad / 64)), dim3(256), 0, stream, p);
+  SV_LAUNCH_CHECK();
+  note_instance("conv_first_mfma_kernel<3, 32>|fast=1,ring=0,full=1");
+  return SV_OK;
 }
 
 static int launch_conv_first_layer(const ConvParams& p, hipStream_t stream) {
@@ -1374,7 +1481,11 @@ extern "C" int sv_conv_fwd(const float* in, int64_t V_in, int64_t in_ld, int Cin
   p.main_blocks = 0;
   p.main_tiles128 = 0;
   static const bool no_first = getenv("SV_CONV_NO_FIRST") != nullptr;  // experiments only
-  if (has_plan && K > 1 && K <= 27 && Cin == 3 && Cout == 32 && !no_first) return launch_conv_first_layer(p, stream);
+  static const bool first_valu = getenv("SV_CONV_FIRST_VALU") != nullptr;  // experiments only: the thread-per-voxel kernel
+  if (has_plan && K > 1 && K <= 27 && Cin == 3 && Cout == 32 && !no_first) {
+    if (p.buf_ok && !first_valu) return launch_conv_first_mfma(p, stream);
+    return launch_conv_first_layer(p, stream);
+  }
   static const bool no_thin = getenv("SV_CONV_NO_THIN") != nullptr;  // experiments only
   if (has_plan && K > 1 && K <= 32 && Cin == 32 && Cout == 32 && p.vec_a && p.buf_ok && !no_thin) return launch_conv_thin(p, stream);
   static const bool no_narrow = getenv("SV_CONV_NO_NARROW") != nullptr;  // experiments only

@@ -47,7 +47,7 @@ def conv_kernel_config(Cout, Vpad, Cin=None, K=1):
     if K == 1 and Cout <= 4 and Cin is not None and Cin >= 64 and Cin % 4 == 0:
         return f"linear_narrow_kernel<{Cout}>"  # dense rows only; every K = 1 layer of the path is dense
     if K > 1 and Cin == 3 and Cout == 32:
-        return "conv_first_layer_kernel<3, 32>"
+        return "conv_first_mfma_kernel<3, 32>"  # (SV_CONV_FIRST_VALU: the thread-per-voxel VALU kernel it replaced)
     if K > 1 and Cin == 32 and Cout == 32:
         return "conv_thin_kernel<32, 32>"  # wave-per-sub-tile direct-gather kernel of the thin 32-channel layers
     fused = None

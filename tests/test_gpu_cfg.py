@@ -115,7 +115,7 @@ def test_cfg2_full_network_bit_exact(gpu, oracle, cfg2):
     used = set(rec.names)
     for inst in ("conv_fwd_dual_kernel<64, 32, 4, 3>", "conv_fwd_kernel<64, 4, 3>",
                  "conv_fwd_kernel<16, 4, 3>", "conv_fwd_kernel<128, 4, 2>",
-                 "conv_first_layer_kernel<3, 32>", "linear_narrow_kernel<3>"):
+                 "conv_first_mfma_kernel<3, 32>", "linear_narrow_kernel<3>"):
         assert inst in used, (inst, sorted(used))
     sd = {k: v.cpu() for k, v in model.state_dict().items()}
     ref = oracle.predict_segmentation(sd, cfg2["pts"], cfg2["rgb"], 50)

@@ -24,7 +24,7 @@ span = (t_end - min(r[0] for r in win)) / 1e6
 
 def short(n):
     s = n
-    for pat in (r"conv_fwd_kernel<[^>]*>", r"conv_first_layer_kernel", r"linear_narrow_kernel", r"sv::(\w+)",
+    for pat in (r"conv_fwd_kernel<[^>]*>", r"conv_first_layer_kernel", r"conv_first_mfma_kernel", r"linear_narrow_kernel", r"sv::(\w+)",
                 r"rocprim::detail::(\w+)", r"at::native::(\w+)", r"(\w+_kernel\w*)"):
         m = re.search(pat, n)
         if m:
