@@ -441,6 +441,13 @@ __device__ __forceinline__ void conv_tile_body(const ConvParams& p, const int bi
           const f32x4 v = buffer_load_floats<4>(rsrc_in, off + (uint32_t)(a_cc % (CPO ? CPO : 1)) * 4u, 0u);
           ra[j] = make_float4(v[0], v[1], v[2], v[3]);
         } else {
+#ifdef SV_EXP_ASKIP
+          // experiment: a wave's j-th gather covers rows of ONE sub-tile ((a_r >> 4) + ROWS_PER_PASS / 16 * j, wave-uniform
+          // when ROWS_PER_PASS is a multiple of 16); skip it - and its LDS store - when that sub-tile is inactive at this step
+          if (ROWS_PER_PASS % 16 == 0 && TM_ >= 32 &&
+              !((sm >> __builtin_amdgcn_readfirstlane((a_r >> 4) + (ROWS_PER_PASS / 16) * j)) & 1u))
+            continue;
+#endif
           const uint32_t off = (uint32_t)idx_s[k * TM_ + rr];
           // the last chunk of a layer whose Cin is not a multiple of KC: columns past Cin are never multiplied; their
           // lanes re-read the row's first columns (col_last) so that no load reaches past a row
@@ -489,6 +496,11 @@ __device__ __forceinline__ void conv_tile_body(const ConvParams& p, const int bi
       const int r = a_r + ROWS_PER_PASS * j;
       // FAST: rows of sub-tiles that are inactive at this offset arrive as zeros and are stored like the others (their
       // matrix ops are skipped anyway) - no per-row mask arithmetic in the loop
+#ifdef SV_EXP_ASKIP
+      if (FAST && !CPO && ROWS_PER_PASS % 16 == 0 && TM_ >= 32 &&
+          !((sm >> __builtin_amdgcn_readfirstlane((a_r >> 4) + (ROWS_PER_PASS / 16) * j)) & 1u))
+        continue;
+#endif
       if (r < TM_ && (FAST || ((sm >> (r >> 4)) & 1u))) {
         float2* dst = (float2*)(dstbuf + r * SA + a_cc);
         dst[0] = make_float2(ra[j].x, ra[j].y);
