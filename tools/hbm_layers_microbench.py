@@ -56,6 +56,8 @@ for label, env in (("default", {}), ("conv0 VALU kernel", {"SV_CONV_FIRST_VALU":
                    ("thin variant 1 (16 cols per wave, D=4)", {"SV_THIN_VARIANT": "1"}),
                    ("thin variant 2 (16 cols, D=6)", {"SV_THIN_VARIANT": "2"}), ("thin variant 3 (16 cols, D=8)", {"SV_THIN_VARIANT": "3"}),
                    ("thin variant 4 (32 cols, D=8)", {"SV_THIN_VARIANT": "4"})):
+    if len(sys.argv) > 1 and label != "default" and env.get("SV_THIN_VARIANT") not in sys.argv[1:]:
+        continue  # `python tools/hbm_layers_microbench.py 5 6`: the default and those thin-kernel variants only
     print(label, flush=True)
     path = os.path.join(tmp, label.split()[0] + str(len(env)) + "".join(env.values()) + ".npz")
     r = subprocess.run([sys.executable, __file__, "child", path], env=dict(os.environ, **env), capture_output=True, text=True)
