@@ -256,3 +256,61 @@ def test_epilogue_every_combination_same_bits(gpu, oracle, cin, cout):
                     same = np.array_equal(got.view(np.int32), want.view(np.int32))
                     assert same, (use_scale, use_shift, use_res, act,
                                   int((got.view(np.int32) != want.view(np.int32)).sum()), np.abs(got - want).max())
+
+
+def test_batch_range_plans_equal_whole_map_launches(gpu, monkeypatch):
+    """ConvPlan.chunks (tensors beyond the 2 GB extent run as batch ranges with their own plans, sv_plan_build nbr_base):
+    with the extent limit lowered so that a 7-frame batch of small frames has to be split - frames of different sizes, one
+    EMPTY batch index in the middle, a frame count that is not a power of two - every kernel map kind (3x3x3, stride-2
+    down, transposed up) gives the bits of the single whole-map launch, with BN, residual and a strided output."""
+    import mrcc_amd
+    from mrcc_amd import MinkowskiEngine as ME
+    from mrcc_amd import nn as svnn
+    from mrcc_amd import sparse
+
+    parts = []
+    for b, n in enumerate((3000, 500, 0, 4200, 1500, 2600, 900)):
+        if n:
+            pts, rgb, _ = mrcc_amd.synth.gen_room(n, 0.5, 50 + b)
+            parts.append((np.concatenate([np.full((n, 1), b, np.float32), pts * np.float32(50)], axis=1), rgb))
+    coords = torch.from_numpy(np.concatenate([p[0] for p in parts]))
+    feats = torch.from_numpy(np.concatenate([p[1] for p in parts]))
+    x = ME.TensorField(feats, coords, device=gpu).sparse()
+    cm = x.coordinate_manager
+    cm.plan_down(1)
+    V0, V1 = cm.stride_map(1).V, cm.stride_map(2).V
+    torch.manual_seed(3)
+    split_seen = False
+    cases = [("k3", cm.plan_k3(1), V0, V0, 27), ("k3 level 1", cm.plan_k3(2), V1, V1, 27), ("down", cm.plan_down(1), V0, V1, 8),
+             ("up", cm.plan_up(2), V1, V0, 8)]
+    for name, plan, V_in, V_out, K in cases:
+        for cin, cout in ((64, 96), (32, 32), (3, 32)):
+            f = torch.randn(V_in, cin, device=gpu)
+            W = torch.randn(K, cin, cout, device=gpu) * 0.1
+            sc, sh = torch.rand(cout, device=gpu) + 0.5, torch.randn(cout, device=gpu)
+            res = torch.randn(V_out, cout, device=gpu)
+            whole = svnn.conv_forward(f, W, plan, V_out, sc, sh, res, 1)
+            assert plan.chunks(4 * cin, 4 * cout) is None  # fits: one launch
+            bi, bo = cm.batch_bounds(plan.in_stride), cm.batch_bounds(plan.out_stride)
+            biggest = max(max(bi[c + 1] - bi[c] for c in range(7)) * 4 * cin, max(bo[c + 1] - bo[c] for c in range(7)) * 4 * (cout + 5))
+            for factor in (1.01, 2.2, 4.5):  # one frame per range, two, four
+                monkeypatch.setattr(sparse, "BUF_LIMIT", int(biggest * factor))
+                plan._chunked.clear()
+                buf = torch.full((V_out, cout + 5), 7.0, device=gpu)  # strided output: a column slice of a wider buffer
+                got = svnn.conv_forward(f, W, plan, V_out, sc, sh, res, 1, out=buf[:, 2:2 + cout])
+                parts_ = plan.chunks(4 * cin, 4 * (cout + 5))
+                fits = V_in * 4 * cin < sparse.BUF_LIMIT and V_out * 4 * (cout + 5) < sparse.BUF_LIMIT
+                assert (parts_ is None) == fits, (name, factor)
+                if parts_ is not None:
+                    assert 2 <= len(parts_) <= 6 and sum(o1 - o0 for _, _, _, o0, o1 in parts_) == V_out
+                    split_seen = True
+                assert torch.equal(got, whole), (name, cin, cout, factor)
+                assert (buf[:, :2] == 7.0).all() and (buf[:, 2 + cout:] == 7.0).all()
+            monkeypatch.setattr(sparse, "BUF_LIMIT", 0x7fff0000 - 4096)
+            plan._chunked.clear()
+    assert split_seen
+    # a single frame beyond the limit cannot be split: chunks() says so and the launch still runs (guarded form)
+    monkeypatch.setattr(sparse, "BUF_LIMIT", 1000)
+    plan = cm.plan_k3(1)
+    plan._chunked.clear()
+    assert plan.chunks(4 * 64, 4 * 64) is None
