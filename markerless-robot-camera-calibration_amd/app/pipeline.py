@@ -135,8 +135,8 @@ class _HostSlot:
         self.uploaded = None  # event: the slot's H2D copies have finished (safe to refill)
 
     def reserve(self, n, channels):
-        if n > self.cap or self.rgb.shape[1] != channels:
-            self.cap = max(n, int(self.cap * 1.25))
+        if self.rgb is None or n > self.cap or self.rgb.shape[1] != channels:
+            self.cap = max(n, int(self.cap * 1.25), 1)
             self.pts = torch.empty((self.cap, 3), dtype=torch.float32).pin_memory()
             self.rgb = torch.empty((self.cap, channels), dtype=torch.float32).pin_memory()
             self.labels = torch.empty(self.cap, dtype=torch.int64).pin_memory()
