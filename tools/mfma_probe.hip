@@ -219,7 +219,71 @@ __global__ __launch_bounds__(256) void mfma_ld_kernel(float* out, const float* w
     if (s == 123.456f) out[0] = s;
 }
 
+// v_mfma_f32_4x4x1_16B_f32: 16 blocks of 4 x 4 x 1 per instruction (512 flop, 8 cycles: the same 64 flop / cycle / SIMD as
+// 16x16x4).  With A broadcast over the column groups and B over the row groups, one instruction is a 16 x 16 output tile at
+// K = 1 whose rows could be skipped in groups of FOUR (row-slot efficiency 0.872 -> 0.943 on the level-0 plan) - at four
+// times the operand instructions per flop.  FEED 0: registers only (is the peak really the same?); 1: the four A operands
+// of a k from LDS (one ds_read_b32 each, reused by three column tiles); 2: plus the k's three B operands as one
+// buffer_load_dwordx3 from a cache-resident block - the per-k operand traffic a conv step in this form would have.
+template <int FEED>
+__global__ __launch_bounds__(256) void mfma_4x4_kernel(float* out, const float* wbuf, int iters) {
+    __shared__ float tile[64 * 36];
+    for (int i = threadIdx.x; i < 64 * 36; i += 256) tile[i] = 1e-9f * i;
+    __syncthreads();
+    f32x4 acc[4][3];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int lane = threadIdx.x & 63;
+    const int blk = lane >> 2, i4 = lane & 3, rg = blk >> 2, cg = blk & 3;
+    float a[4] = {1e-9f * lane, 2e-9f * lane, 3e-9f, 4e-9f};
+    f32x3 b = {1.0f, 1.0f + 1e-9f * blockIdx.x, 0.5f};
+    i32x4 srd;
+    srd[0] = (int)(unsigned)(unsigned long long)wbuf;
+    srd[1] = (int)(unsigned)((unsigned long long)wbuf >> 32);
+    srd[2] = 1 << 18;
+    srd[3] = 0x00020000;
+    const unsigned voff = (unsigned)((cg * 4 + i4) * 3 + (threadIdx.x >> 6) * 48) * 4u;
+    f32x3 wv[8];
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            if (FEED >= 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            if (FEED >= 1) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) a[m] = tile[(m * 16 + rg * 4 + i4) * 36 + k];
+            }
+            const f32x3 bk = FEED >= 2 ? wv[k & 7] : b;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 3; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[m], bk[n], acc[m][n], 0, 0, 0);
+            if (FEED >= 2)
+                asm volatile("buffer_load_dwordx3 %0, %1, %2, 0 offen" : "=v"(wv[k & 7]) : "v"(voff + (unsigned)k * 384u * 4u), "s"(srd) : "memory");
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float s = 0.f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) s += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
+    if (FEED >= 2) s += wv[0][0] + wv[7][2];
+    if (s == 123.456f) out[0] = s;
+}
+
 extern "C" {
+// returns 4x4x1 matrix ops per wave per launch (512 flop each)
+long long mfma_4x4_launch(int feed, int blocks, int iters, float* out, const float* wbuf, hipStream_t stream) {
+    switch (feed) {
+        case 0: hipLaunchKernelGGL(mfma_4x4_kernel<0>, dim3(blocks), dim3(256), 0, stream, out, wbuf, iters); break;
+        case 1: hipLaunchKernelGGL(mfma_4x4_kernel<1>, dim3(blocks), dim3(256), 0, stream, out, wbuf, iters); break;
+        case 2: hipLaunchKernelGGL(mfma_4x4_kernel<2>, dim3(blocks), dim3(256), 0, stream, out, wbuf, iters); break;
+        default: return -1;
+    }
+    return 32LL * 12 * iters;
+}
 long long mfma_ld_launch(int ld, int blocks, int iters, float* out, const float* wbuf, hipStream_t stream) {
 #define LDK(M) case M: hipLaunchKernelGGL(mfma_ld_kernel<M>, dim3(blocks), dim3(256), 0, stream, out, wbuf, iters); break;
     switch (ld) {

@@ -70,6 +70,23 @@ def main():
             tf_tail, tf_head, state, n = timed(seconds, launch, flop)
             print(f"mfma 16x16x4 f32, {name}, {waves} wave(s)/SIMD: settled {tf_tail:6.1f} TFLOP/s "
                   f"(first quarter {tf_head:6.1f}; {n} launches) = {tf_tail / 157.3:.3f} of 157.3 | {state}", flush=True)
+    # v_mfma_f32_4x4x1_16B_f32 (4-row skip granularity at the same nominal peak): registers only, A from LDS, A + B fed per k
+    lib.mfma_4x4_launch.restype = ctypes.c_longlong
+    lib.mfma_4x4_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    wb = torch.randn(1 << 16, device=dev)
+    for feed, name in ((0, "registers only"), (1, "4 ds_read_b32 per k (A, reused by 3 column tiles)"),
+                       (2, "4 ds_read_b32 + 1 buffer_load_dwordx3 per k (A and B: a conv step's operand traffic)")):
+        for waves in (2, 4):
+            blocks, iters = 256 * waves, 1000
+            ops = lib.mfma_4x4_launch(feed, blocks, 1, out.data_ptr(), wb.data_ptr(), stream)
+            flop = ops * iters * blocks * 4 * 512.0
+
+            def launch():
+                lib.mfma_4x4_launch(feed, blocks, iters, out.data_ptr(), wb.data_ptr(), stream)
+            tf_tail, tf_head, state, n = timed(min(seconds, 2.0), launch, flop)
+            print(f"mfma 4x4x1 16B f32, {name}, {waves} waves/SIMD: {tf_tail:6.1f} TFLOP/s = {tf_tail / 157.3:.3f} of 157.3", flush=True)
+    if "--4x4-only" in sys.argv:
+        return
     # the same LDS-fed loop with one more instruction class at a time (tools/mfma_probe.hip, mfma_mix_kernel)
     lib.mfma_mix_launch.restype = ctypes.c_longlong
     lib.mfma_mix_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_longlong, ctypes.c_void_p]
