@@ -660,8 +660,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region (exactly --steps steps between barrier + synchronize) is run this many times; "
-                         "ms_per_step is the median, min / max are on the line.  More repeats are added until the timed "
-                         "regions total >= 1 s")
+                         "ms_per_step is the median, min / max are on the line.  Small --steps get more repeats "
+                         "(ceil(64 / steps)) so that the timed regions total about a second or more")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pool", type=int, default=4, help="distinct frames resident per rank")
     ap.add_argument("--no-kernel-timer", action="store_true", help="diagnostic: drop the per-launch HIP events")
@@ -821,18 +821,12 @@ def main():
             else:
                 timer.records += timer_r.records
 
-        repeats = max(1, args.repeats)
+        # R repeats; short regions (small --steps) get more of them so that the timed regions total about a second or more.
+        # The count is a pure function of the arguments - identical on every rank without a collective (the run's only
+        # collective stays the one all_gather of the metrics record; the barriers are the contract's).
+        repeats = min(max(1, args.repeats, -(-64 // max(args.steps * args.frames_per_step, 1))), 64)
         _log(f"warm-up done; timing {args.steps} steps x {repeats} repeats")
         for _ in range(repeats):
-            timed_region()
-        # short regions (small --steps): more repeats until the timed regions total >= 1 s.  The count must be identical on
-        # every rank (each repeat contains barriers), so rank 0 decides and broadcasts it.
-        need = int(math.ceil(1.0 / max(sum(elapsed_list) / len(elapsed_list), 1e-6)))
-        if world > 1:
-            t = torch.tensor([need], dtype=torch.int64, device=device if backend == "nccl" else "cpu")
-            dist.broadcast(t, 0)
-            need = int(t.item())
-        for _ in range(min(need, 50) - repeats):
             timed_region()
     elapsed = _median(elapsed_list)
     _log(f"timed regions: median {elapsed * 1e3 / args.steps:.2f} ms/step over {len(elapsed_list)} repeats "
