@@ -516,7 +516,13 @@ def other_configs_block(model, device, streams, checked):
     from mrcc_amd.app.pipeline import FramePipeline
     from mrcc_amd.utils import transformation as T
 
+    from mrcc_amd.model.robotnet_vote import RobotNetVote
+
     out = {}
+    torch.manual_seed(4)
+    vote = RobotNetVote(3).to(device).eval()
+    crop1 = mrcc_amd.synth.gen_ee_crop(0, n=16)
+    kp_ref1, kp_tgt1 = mrcc_amd.synth.REFERENCE_KEY_POINTS[None], crop1[3][None]
     # ---- Cfg-5
     _log("other configs: cfg5 (500k points, 1 cm)")
     frames5 = []
@@ -534,6 +540,31 @@ def other_configs_block(model, device, streams, checked):
         vox5 = run_frames(model, pipe, frames5, n5)
         torch.cuda.synchronize()
         dt5 = (time.perf_counter() - t0) / n5
+
+        # the configuration as BASELINE words it - seg -> vote -> pose: the vote head (model/robotnet_vote.py:62-71) on the
+        # same sparse tensor and one Kabsch solve per frame (the pose legs on the end-effector crop are parity-tested at
+        # this size in tests/test_gpu_cfg.py; their networks see a few thousand points)
+        def seg_vote_pose(x_, f_):
+            lab_ = model(x_).slice_argmax(f_)[0]
+            v_ = vote(x_).slice_argmax(f_)[0]
+            T.get_rigid_transform_3D_batched(kp_ref1, kp_tgt1, device=device)
+            return lab_, v_
+
+        def run5(n):
+            nxt = pipe.prepare(*frames5[0][:2])
+            for i in range(n):
+                cur = nxt
+                pipe.run(cur, seg_vote_pose)
+                if i + 1 < n:
+                    nxt = pipe.prepare(*frames5[(i + 1) % len(frames5)][:2])
+            pipe.drain()
+
+        run5(2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run5(6)
+        torch.cuda.synchronize()
+        dt5_full = (time.perf_counter() - t0) / 6
         # parity on frame 0
         field = ME.TensorField(frames5[0][1], frames5[0][0], device=device)
         x = field.sparse()
@@ -555,8 +586,11 @@ def other_configs_block(model, device, streams, checked):
                     sd_["regression.2.linear.bias"].numpy())
         lg = logits.F.cpu().numpy()
         out["cfg5"] = {
-            "workload": "cfg5: 500k-pt cloud, 1 cm voxels, seg U-Net forward (voxelise + maps + U-Net + slice/argmax)",
-            "value": round(1.0 / dt5, 3), "unit": "frames/s", "ms_per_frame": round(dt5 * 1e3, 3), "frames_timed": n5,
+            "workload": "cfg5: 500k-pt cloud, 1 cm voxels, seg -> vote -> pose: voxelise + maps, RobotNetSegmentation and "
+                        "RobotNetVote (both MinkUNet18D heads) on the frame, slice/argmax of both, one Kabsch solve",
+            "value": round(1.0 / dt5_full, 3), "unit": "frames/s", "ms_per_frame": round(dt5_full * 1e3, 3), "frames_timed": 6,
+            "seg_only": {"value": round(1.0 / dt5, 3), "unit": "frames/s", "ms_per_frame": round(dt5 * 1e3, 3), "frames_timed": n5,
+                         "what": "voxelise + maps + seg U-Net + slice/argmax (the headline pipeline at 3.5x the voxels)"},
             "active_voxels_per_frame": int(vox5 // n5),
             "parity": {"voxel_keys_equal": bool(np.array_equal(x.coordinate_map.keys.cpu().numpy().view(np.uint64), vox["keys"])),
                        "inverse_equal": bool(np.array_equal(field.inverse_mapping.cpu().numpy(), vox["inverse"])),
@@ -573,11 +607,13 @@ def other_configs_block(model, device, streams, checked):
         kp_ref = np.repeat(mrcc_amd.synth.REFERENCE_KEY_POINTS[None], B, axis=0)
         kp_tgt = np.stack([c[3] for c in crops])
 
-        def step3():
+        def step3(with_vote=False):
             f = ME.TensorField(feats_in, coords, device=device)
             xs = f.sparse()
             o = model(xs)
             lab = o.slice_argmax(f)[0]
+            if with_vote:
+                vote(xs).slice_argmax(f)
             R, t, q = T.get_rigid_transform_3D_batched(kp_ref, kp_tgt, device=device)
             return xs, o, lab, (R, t, q)
 
@@ -604,10 +640,18 @@ def other_configs_block(model, device, streams, checked):
             step3()
         torch.cuda.synchronize()
         dt3 = (time.perf_counter() - t0) / n3
+        step3(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step3(True)
+        torch.cuda.synchronize()
+        dt3_full = time.perf_counter() - t0
         out["cfg3"] = {
-            "workload": f"cfg3: {B} synthetic 200k-pt frames in ONE sparse tensor (batch column), seg U-Net forward + "
-                        f"slice/argmax + {B} Kabsch problems",
-            "value": round(B / dt3, 3), "unit": "frames/s", "ms_per_batch": round(dt3 * 1e3, 2), "batches_timed": n3,
+            "workload": f"cfg3: {B} synthetic 200k-pt frames in ONE sparse tensor (batch column): seg + keypoint-vote (two "
+                        f"MinkUNet18D heads on the batch) + slice/argmax of both + {B} Kabsch problems",
+            "value": round(B / dt3_full, 3), "unit": "frames/s", "ms_per_batch": round(dt3_full * 1e3, 2), "batches_timed": 1,
+            "seg_only": {"value": round(B / dt3, 3), "unit": "frames/s", "ms_per_batch": round(dt3 * 1e3, 2), "batches_timed": n3,
+                         "what": f"seg U-Net forward + slice/argmax + {B} Kabsch problems"},
             "active_voxels": int(V3),
             "parity": {"frame0_equals_single_frame_run_bit_exact": same, "frame0_labels_equal_oracle": oracle_labels,
                        "all_wide_layer_launches_on_fast_instances": bool(wide and all(e[1]["fast"] == 1 for e in wide)),
