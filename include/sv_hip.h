@@ -60,7 +60,8 @@ typedef void* sv_stream_t;
 
 const char* sv_last_error(void);
 /* 2: sv_conv_fwd takes V_in (rows of `in`); sv_single_linkage_roots / sv_select_equal added
- * 3: sv_plan_build takes nbr_base (plans of a batch range of a kernel map); sv_key_point_predictions added */
+ * 3: sv_plan_build takes nbr_base (plans of a batch range of a kernel map); sv_key_point_predictions,
+ *    sv_conv_last_instance and sv_conv_fwd_acc (offset-range passes of one layer) added */
 #define SV_ABI_VERSION 3
 int sv_abi_version(void);
 
@@ -159,6 +160,18 @@ int sv_conv_fwd(const float* in, int64_t V_in, int64_t in_ld, int Cin, const flo
                 const float* scale,
                 const float* shift, const float* residual, int64_t res_ld, int act, float slope, float* out,
                 int64_t out_ld, sv_stream_t stream);
+/* The same layer with its chains CONTINUED from an earlier launch: acc_init[o][n] (row stride acc_ld, NULL = start at 0) is
+ * the raw accumulator of output element (o, n) over the kernel offsets that precede this launch's - the caller splits the K
+ * offsets of a layer into ascending ranges, runs every range with its own plan (its own row order: rows that share their
+ * neighbours among 13-14 offsets group far better into 16-row matrix-op sub-tiles than rows that must share all 27:
+ * 0.87 -> 0.96 useful row slots on the 2 cm room level) and weight block W + k0 * Cin * Cout, the first ranges with no
+ * epilogue at all (scale = shift = residual = NULL, act = none: `out` then IS the raw accumulator), the last one with
+ * acc_init = that buffer and the layer's epilogue.  The matrix op takes acc_init as its C operand, so every output
+ * element is still ONE fma chain over (k ascending, c ascending): the result has the bits of the single launch. */
+int sv_conv_fwd_acc(const float* in, int64_t V_in, int64_t in_ld, int Cin, const float* W, int K, int Cout, const int32_t* perm,
+                    const int32_t* nbr_s, const uint32_t* submask, const int32_t* tile_order, int64_t V_out, int64_t Vpad,
+                    const float* acc_init, int64_t acc_ld, const float* scale, const float* shift, const float* residual,
+                    int64_t res_ld, int act, float slope, float* out, int64_t out_ld, sv_stream_t stream);
 /* Kernel instance the calling thread's last sv_conv_fwd launched: "name|fast=F,ring=R,full=U" (fast = buffer-addressed
  * form; a tensor beyond its 2 GB extent, a misaligned plan or an odd channel count takes the guarded form).  Tests and the
  * bench's per-kernel table read it back instead of re-deriving the dispatch. */

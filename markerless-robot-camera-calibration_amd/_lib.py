@@ -47,6 +47,11 @@ SIGNATURES = {
         [_P, c_int64, c_int64, c_int, _P, c_int, c_int, _P, _P, _P, _P, c_int64, c_int64, _P, _P, _P, c_int64, c_int,
          c_float, _P, c_int64, _P],
     ),
+    "sv_conv_fwd_acc": (
+        c_int,
+        [_P, c_int64, c_int64, c_int, _P, c_int, c_int, _P, _P, _P, _P, c_int64, c_int64, _P, c_int64, _P, _P, _P, c_int64, c_int,
+         c_float, _P, c_int64, _P],
+    ),
     "sv_conv_last_instance": (c_char_p, []),
     "sv_affine_act": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, _P, c_int64, c_int, c_float, _P, c_int64, _P]),
     "sv_col_stats_workspace_bytes": (c_size_t, [c_int64]),

@@ -36,6 +36,13 @@ def build_unet_plans(cm, levels=4):
     cm.plan_k3(1 << levels)
     for l in range(levels, 0, -1):
         cm.plan_up(1 << l)
+    # the two-pass plans of the wide decoder layers on big levels (nn.SPLIT_MIN_ROWS) are built here, on the prep stream
+    from .. import nn as svnn
+
+    for l in range(levels):
+        cuts = svnn.split_points_for(cm.stride_map(1 << l).V)
+        if cuts is not None:
+            cm.plan_k3_split(1 << l, cuts)
 
 
 class FramePipeline:

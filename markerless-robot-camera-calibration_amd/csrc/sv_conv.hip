@@ -44,6 +44,13 @@ struct ConvParams {
   const float* shift;
   const float* residual;
   int64_t res_ld;
+  // accumulator hand-over between the passes of a layer whose kernel offsets are split into ascending ranges (each range
+  // with its own plan / row order): acc_init[o][n] = the raw fma chain over the EARLIER offsets of output element (o, n); it
+  // is the matrix op's C operand at the start of this launch's chain, so the chain over all offsets is the one chain it
+  // always was.  NULL = the chain starts at 0.
+  const float* acc_init;
+  int64_t acc_ld;
+  uint32_t acc_bytes;
   int act;
   float slope;
   float* out;
@@ -312,6 +319,33 @@ __device__ __forceinline__ void conv_tile_body(const ConvParams& p, const int bi
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[s][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // ---- continue an earlier pass's chains: C operands from acc_init, addressed through `perm` like the epilogue's rows
+  if (p.acc_init) {
+    if constexpr (FAST) {
+      const __amdgpu_buffer_rsrc_t rsrc_acc = __builtin_amdgcn_make_buffer_rsrc((void*)p.acc_init, 0, (int)p.acc_bytes, 0x00020000);
+      int o_acc[MR][4];
+      load_perm_rows<MR>(p, row0 + wm * MR * 16, lane >> 4, o_acc);
+#pragma unroll
+      for (int s = 0; s < MR; ++s)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const auto v = buffer_load_floats<NT>(
+              rsrc_acc, o_acc[s][reg] >= 0 ? (uint32_t)o_acc[s][reg] * (uint32_t)(p.acc_ld * 4) + (uint32_t)col0 * 4u : BUF_ABSENT, 0u);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[s][n][reg] = v[n];
+        }
+    } else {
+#pragma unroll
+      for (int s = 0; s < MR; ++s)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int64_t r = row0 + wm * MR * 16 + s * 16 + (lane >> 4) * 4 + reg;
+          const int64_t o = p.perm ? (int64_t)p.perm[r] : (r < p.V_out ? r : -1);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[s][n][reg] = (o >= 0 && col0 + n < Cout) ? p.acc_init[o * p.acc_ld + col0 + n] : 0.0f;
+        }
+    }
+  }
   // ---- stage the tile's neighbour table (or the identity for dense rows) in LDS
   uint32_t dense_mask = (1u << SUBS) - 1u;
   if (p.submask == nullptr) {
@@ -1438,7 +1472,17 @@ extern "C" int sv_conv_fwd(const float* in, int64_t V_in, int64_t in_ld, int Cin
                            const int32_t* perm, const int32_t* nbr_s, const uint32_t* submask,
                            const int32_t* tile_order, int64_t V_out, int64_t Vpad, const float* scale, const float* shift, const float* residual, int64_t res_ld,
                            int act, float slope, float* out, int64_t out_ld, sv_stream_t stream_) {
+  return sv_conv_fwd_acc(in, V_in, in_ld, Cin, W, K, Cout, perm, nbr_s, submask, tile_order, V_out, Vpad, nullptr, 0, scale, shift,
+                         residual, res_ld, act, slope, out, out_ld, stream_);
+}
+
+extern "C" int sv_conv_fwd_acc(const float* in, int64_t V_in, int64_t in_ld, int Cin, const float* W, int K, int Cout,
+                               const int32_t* perm, const int32_t* nbr_s, const uint32_t* submask, const int32_t* tile_order,
+                               int64_t V_out, int64_t Vpad, const float* acc_init, int64_t acc_ld, const float* scale,
+                               const float* shift, const float* residual, int64_t res_ld, int act, float slope, float* out,
+                               int64_t out_ld, sv_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  SV_CHECK_ARG(!acc_init || acc_ld >= Cout, "acc_init stride too small");
   SV_CHECK_ARG(Cin > 0 && Cout > 0 && K >= 1 && K <= 32, "bad channel / kernel volume");
   SV_CHECK_ARG(V_out >= 0 && Vpad >= V_out && Vpad % PLAN_TILE == 0, "Vpad must be a multiple of 128 >= V_out");
   SV_CHECK_ARG(in_ld >= Cin && out_ld >= Cout, "row strides too small");
@@ -1454,6 +1498,7 @@ extern "C" int sv_conv_fwd(const float* in, int64_t V_in, int64_t in_ld, int Cin
   p.in = in; p.in_ld = in_ld; p.Cin = Cin; p.W = W; p.K = K; p.Cout = Cout;
   p.perm = perm; p.nbr_s = nbr_s; p.submask = submask; p.tile_order = tile_order; p.V_out = V_out; p.Vpad = Vpad;
   p.scale = scale; p.shift = shift; p.residual = residual; p.res_ld = res_ld;
+  p.acc_init = acc_init; p.acc_ld = acc_ld;
   p.act = act; p.slope = slope; p.out = out; p.out_ld = out_ld;
   p.vec_a = (in_ld % 4 == 0) && (Cin % 4 == 0) && (((uintptr_t)in & 15) == 0);
   // extents for the buffer descriptors of the FAST instances: `in` through the last channel of its last row
@@ -1461,10 +1506,12 @@ extern "C" int sv_conv_fwd(const float* in, int64_t V_in, int64_t in_ld, int Cin
   const uint64_t w_bytes = (uint64_t)K * (uint64_t)Cin * (uint64_t)Cout * 4u;
   const uint64_t out_bytes = ((uint64_t)(V_out - 1) * (uint64_t)out_ld + (uint64_t)Cout) * 4u;
   const uint64_t res_bytes = residual ? ((uint64_t)(V_out - 1) * (uint64_t)res_ld + (uint64_t)Cout) * 4u : 0u;
+  const uint64_t acc_bytes = acc_init ? ((uint64_t)(V_out - 1) * (uint64_t)acc_ld + (uint64_t)Cout) * 4u : 0u;
   // (the buffer-addressed epilogue reads `perm` four entries at a time: a plan carved from a workspace at an odd offset
   //  takes the guarded form)
   p.buf_ok = in_bytes < BUF_LIMIT && w_bytes < BUF_LIMIT && out_bytes < BUF_LIMIT && res_bytes < BUF_LIMIT &&
-             (((uintptr_t)perm & 15) == 0);
+             acc_bytes < BUF_LIMIT && (((uintptr_t)perm & 15) == 0);
+  p.acc_bytes = p.buf_ok ? (uint32_t)acc_bytes : 0u;
   if (!p.buf_ok && !has_plan && K == 1 && w_bytes < BUF_LIMIT) {
     // dense rows (Linear / 1x1 conv) of a tensor beyond the 2 GB extent: every row range is a layer of its own, so the
     // launch is split into ranges that fit the buffer-addressed instances (64 Cfg-2 frames x 1024 channels = 23 GB)
@@ -1474,10 +1521,10 @@ extern "C" int sv_conv_fwd(const float* in, int64_t V_in, int64_t in_ld, int Cin
     if (rows >= PLAN_TILE && rows < V_out) {
       for (int64_t r0 = 0; r0 < V_out; r0 += rows) {
         const int64_t n = V_out - r0 < rows ? V_out - r0 : rows;
-        const int rc = sv_conv_fwd(in + r0 * in_ld, n, in_ld, Cin, W, K, Cout, nullptr, nullptr, nullptr, nullptr, n,
-                                   (n + PLAN_TILE - 1) / PLAN_TILE * PLAN_TILE, scale, shift,
-                                   residual ? residual + r0 * res_ld : nullptr, res_ld, act, slope, out + r0 * out_ld, out_ld,
-                                   stream_);
+        const int rc = sv_conv_fwd_acc(in + r0 * in_ld, n, in_ld, Cin, W, K, Cout, nullptr, nullptr, nullptr, nullptr, n,
+                                       (n + PLAN_TILE - 1) / PLAN_TILE * PLAN_TILE, acc_init ? acc_init + r0 * acc_ld : nullptr,
+                                       acc_ld, scale, shift, residual ? residual + r0 * res_ld : nullptr, res_ld, act, slope,
+                                       out + r0 * out_ld, out_ld, stream_);
         if (rc != SV_OK) return rc;
       }
       return SV_OK;
@@ -1494,13 +1541,13 @@ extern "C" int sv_conv_fwd(const float* in, int64_t V_in, int64_t in_ld, int Cin
   p.main_tiles128 = 0;
   static const bool no_first = getenv("SV_CONV_NO_FIRST") != nullptr;  // experiments only
   static const bool first_valu = getenv("SV_CONV_FIRST_VALU") != nullptr;  // experiments only: the thread-per-voxel kernel
-  if (has_plan && K > 1 && K <= 27 && Cin == 3 && Cout == 32 && !no_first) {
+  if (has_plan && K > 1 && K <= 27 && Cin == 3 && Cout == 32 && !no_first && !acc_init) {
     if (p.buf_ok && !first_valu) return launch_conv_first_mfma(p, stream);
     return launch_conv_first_layer(p, stream);
   }
   static const bool no_thin = getenv("SV_CONV_NO_THIN") != nullptr;  // experiments only
-  if (has_plan && K > 1 && K <= 32 && Cin == 32 && Cout == 32 && p.vec_a && p.buf_ok && !no_thin) return launch_conv_thin(p, stream);
+  if (has_plan && K > 1 && K <= 32 && Cin == 32 && Cout == 32 && p.vec_a && p.buf_ok && !no_thin && !acc_init) return launch_conv_thin(p, stream);
   static const bool no_narrow = getenv("SV_CONV_NO_NARROW") != nullptr;  // experiments only
-  if (!has_plan && K == 1 && Cout <= 4 && p.vec_a && Cin >= 64 && !no_narrow) return launch_linear_narrow(p, stream);
+  if (!has_plan && K == 1 && Cout <= 4 && p.vec_a && Cin >= 64 && !no_narrow && !acc_init) return launch_linear_narrow(p, stream);
   return select_and_launch(p, stream);
 }

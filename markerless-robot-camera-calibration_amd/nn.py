@@ -17,13 +17,42 @@ import torch.nn as nn
 
 from . import _lib, profiling
 from ._lib import SV_ACT_LEAKY_RELU, SV_ACT_NONE, SV_ACT_RELU, call, ptr, stream_ptr
-from .sparse import SparseTensor
+from .sparse import SparseTensor, SplitPlan
 
 # Adapting a checkpoint written by a MinkowskiEngine build whose kernel-offset numbering differs from this build's
 # (include/sv_hip.h: k = (dx+1) + 3 (dy+1) + 9 (dz+1), x fastest; k = dx + 2 dy + 4 dz for kernel_size 2):
 # {kernel_volume: perm} with  this_build_kernel[k] = checkpoint_kernel[perm[k]].  Applied to every `kernel` of that
 # volume inside load_state_dict (_ConvBase._load_from_state_dict); None = checkpoints already use this numbering.
 KERNEL_OFFSET_PERMUTATION = None
+
+# Wide 3x3x3 layers on big pyramid levels run as PASSES over ascending ranges of the kernel offsets (sparse.SplitPlan), each
+# pass with its own row order: worth it where the matrix-op time saved by the better row grouping (~9 % of the slots at 88k
+# voxels with two passes, ~12 % with three) exceeds the extra launches' fixed costs and the accumulator hand-over
+# (measured inside the frame pipeline: tools/ab_split.sh).  MRCC_SPLIT_RULES = "min_rows:cut[,cut...];..." -
+# the first rule whose min_rows the output map reaches applies; "" = never split.
+import os as _os  # noqa: E402
+
+
+def _parse_split_rules(text):
+    rules = []
+    for part in text.split(";"):
+        if part.strip():
+            rows, _, cuts = part.partition(":")
+            cuts = tuple(int(v) for v in cuts.split(",") if v)
+            rules.append((int(rows), cuts[0] if len(cuts) == 1 else cuts))
+    return sorted(rules, key=lambda r: -r[0])
+
+
+SPLIT_RULES = _parse_split_rules(_os.environ.get("MRCC_SPLIT_RULES", "60000:14;20000:14"))
+SPLIT_MIN_CHANNELS = int(_os.environ.get("MRCC_SPLIT_MIN_CHANNELS", "128"))
+
+
+def split_points_for(rows):
+    """split points of the 3x3x3 layers on an output map of `rows` voxels (None = one pass)"""
+    for min_rows, cuts in SPLIT_RULES:
+        if rows >= min_rows:
+            return cuts
+    return None
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -39,6 +68,42 @@ def conv_forward(feats, weight3, plan, V_out, scale=None, shift=None, residual=N
         feats = feats.contiguous()
     if out is None:
         out = torch.empty((V_out, Cout), dtype=torch.float32, device=feats.device)
+    if isinstance(plan, SplitPlan):
+        return _conv_forward_split(feats, weight3, plan, V_out, scale, shift, residual, act, slope, out)
+    return _conv_forward_one(feats, weight3, plan, V_out, scale, shift, residual, act, slope, out, None)
+
+
+def _conv_forward_split(feats, weight3, plan, V_out, scale, shift, residual, act, slope, out):
+    """A layer as passes over ascending offset ranges (sparse.SplitPlan): every pass but the last writes the raw
+    accumulators (no epilogue), the next one continues the chains from them (sv_conv_fwd_acc)."""
+    K, Cin, Cout = weight3.shape
+    timer = profiling.TIMER
+    t0 = None
+    if timer is not None:
+        kname = profiling.conv_kernel_config(Cout, plan.Vpad, Cin, plan.parts[-1][1] - plan.parts[-1][0])
+        if timer.want(kname):
+            t0 = timer.start()
+    held, profiling.TIMER = profiling.TIMER, None  # the passes are ONE layer for the per-kernel table
+    try:
+        acc = None
+        for i, (k0, k1, sub) in enumerate(plan.parts):
+            last = i == len(plan.parts) - 1
+            w = weight3[k0:k1]
+            if last:
+                _conv_forward_one(feats, w, sub, V_out, scale, shift, residual, act, slope, out, acc)
+            else:
+                nxt = torch.empty((V_out, Cout), dtype=torch.float32, device=feats.device)
+                _conv_forward_one(feats, w, sub, V_out, None, None, None, SV_ACT_NONE, slope, nxt, acc)
+                acc = nxt
+    finally:
+        profiling.TIMER = held
+    if t0 is not None:
+        timer.stop(t0, _lib.conv_last_instance()[0], K, Cin, Cout, V_out, plan.pairs_device(), level=plan.out_stride)
+    return out
+
+
+def _conv_forward_one(feats, weight3, plan, V_out, scale, shift, residual, act, slope, out, acc_init):
+    K, Cin, Cout = weight3.shape
     if plan is None:
         Vpad = (max(V_out, 1) + _lib.SV_TILE_ROWS - 1) // _lib.SV_TILE_ROWS * _lib.SV_TILE_ROWS
     else:
@@ -53,21 +118,24 @@ def conv_forward(feats, weight3, plan, V_out, scale=None, shift=None, residual=N
 
     log = profiling.INSTANCE_LOG
 
-    def launch(f, pl, o, r, v_out, v_pad):
-        call("sv_conv_fwd", ptr(f), c_int64(f.shape[0]), c_int64(f.stride(0)), c_int(Cin), ptr(weight3), c_int(K),
+    acc_ld = acc_init.stride(0) if acc_init is not None else 0
+
+    def launch(f, pl, o, r, v_out, v_pad, a=None):
+        call("sv_conv_fwd_acc", ptr(f), c_int64(f.shape[0]), c_int64(f.stride(0)), c_int(Cin), ptr(weight3), c_int(K),
              c_int(Cout), ptr(pl.perm if pl else None), ptr(pl.nbr_s if pl else None), ptr(pl.submask if pl else None),
-             ptr(pl.tile_order if pl else None), c_int64(v_out), c_int64(v_pad), ptr(scale), ptr(shift), ptr(r),
-             c_int64(res_ld), c_int(act), c_float(slope), ptr(o), c_int64(o.stride(0)), stream_ptr())
+             ptr(pl.tile_order if pl else None), c_int64(v_out), c_int64(v_pad), ptr(a), c_int64(acc_ld), ptr(scale), ptr(shift),
+             ptr(r), c_int64(res_ld), c_int(act), c_float(slope), ptr(o), c_int64(o.stride(0)), stream_ptr())
         if log is not None:  # what the library really launched (sv_conv_last_instance), not a re-derivation
             log.append((*_lib.conv_last_instance(), K, Cin, Cout, v_out))
 
     # batched tensors beyond the 2 GB extent of the buffer-addressed instances run as batch ranges (ConvPlan.chunks)
-    parts = plan.chunks(4 * feats.stride(0), 4 * max(out.stride(0), res_ld)) if plan is not None else None
+    parts = plan.chunks(4 * feats.stride(0), 4 * max(out.stride(0), res_ld, acc_ld)) if plan is not None else None
     if parts is None:
-        launch(feats, plan, out, residual, V_out, Vpad)
+        launch(feats, plan, out, residual, V_out, Vpad, acc_init)
     else:
         for sub, i0, i1, o0, o1 in parts:
-            launch(feats[i0:i1], sub, out[o0:o1], residual[o0:o1] if residual is not None else None, o1 - o0, sub.Vpad)
+            launch(feats[i0:i1], sub, out[o0:o1], residual[o0:o1] if residual is not None else None, o1 - o0, sub.Vpad,
+                   acc_init[o0:o1] if acc_init is not None else None)
     if t0 is not None:
         # recorded under the instance the library reports (the prediction above only decides whether to time at all)
         timer.stop(t0, _lib.conv_last_instance()[0], K, Cin, Cout, V_out,
@@ -176,6 +244,10 @@ class _ConvBase(nn.Module):
             if ks == 1 and st == 1:
                 return None, ts
             if ks == 3 and st == 1:
+                if self.dilation == 1 and self.in_channels >= SPLIT_MIN_CHANNELS and self.out_channels >= SPLIT_MIN_CHANNELS:
+                    cuts = split_points_for(cm.stride_map(ts).V)
+                    if cuts is not None:
+                        return cm.plan_k3_split(ts, cuts), ts
                 return cm.plan_k3(ts, self.dilation), ts
             if ks == 2 and st == 2:
                 return cm.plan_down(ts), ts * 2

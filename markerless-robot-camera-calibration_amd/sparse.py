@@ -126,6 +126,38 @@ class ConvPlan:
         return self._chunked[f]
 
 
+class SplitPlan:
+    """A kernel map run as PASSES over ascending offset ranges, each range with its own plan - its own mask-sorted row
+    order.  Rows that share their neighbours among 13-14 offsets group far better into 16-row matrix-op sub-tiles than rows
+    that must agree on all 27: useful row slots 0.872 -> 0.960 on the 2 cm room level (0.936 -> 0.969 one level up; CPU
+    count, tools/tile_experiment.py).  The passes hand the raw accumulators over through memory (sv_conv_fwd_acc), so every
+    output element stays ONE fma chain over (offset ascending, channel ascending).  parts: [(k0, k1, ConvPlan)]."""
+
+    __slots__ = ("parts", "whole")
+
+    def __init__(self, parts, whole):
+        self.parts, self.whole = parts, whole
+
+    # what callers read off a plan
+    @property
+    def V_out(self):
+        return self.whole.V_out
+
+    @property
+    def Vpad(self):
+        return self.whole.Vpad
+
+    @property
+    def out_stride(self):
+        return self.whole.out_stride
+
+    def pairs_device(self):
+        return self.whole.pairs_device()
+
+    def num_pairs(self):
+        return self.whole.num_pairs()
+
+
 class CoordinateManager:
     def __init__(self, device):
         self.device = device
@@ -205,6 +237,24 @@ class CoordinateManager:
             call("sv_kernel_map_k3", ptr(m.coords), c_int64(V), c_int(stride), c_int(dilation), ptr(tkeys), ptr(tvals),
                  c_int64(cap), ptr(nbr), c_int64(max(V, 1)), ptr(mask), stream_ptr())
             self.plans[key] = self._own(self._build_plan(nbr, max(V, 1), mask, 27, V), nbr, max(V, 1), mask, stride, stride)
+        return self.plans[key]
+
+    def plan_k3_split(self, stride, split=14):
+        """The 3x3x3 map of `stride` as passes over ascending offset ranges (SplitPlan): split = 14 -> [0, 14) and [14, 27)
+        (the centre offset in the first pass; the best two-pass split on the room levels, 13 equal); a tuple of split
+        points gives more passes."""
+        cuts = (split,) if isinstance(split, int) else tuple(split)
+        key = ("k3split", stride, split)
+        if key not in self.plans:
+            whole = self.plan_k3(stride)
+            nbr, ld, mask = whole.raw
+            parts = []
+            bounds = (0,) + cuts + (27,)
+            for k0, k1 in zip(bounds[:-1], bounds[1:]):
+                sub = ((mask >> k0) & ((1 << (k1 - k0)) - 1)).to(torch.int32)
+                plan = self._build_plan(nbr[k0:k1], ld, sub, k1 - k0, whole.V_out)
+                parts.append((k0, k1, self._own(plan, nbr[k0:k1], ld, sub, stride, stride)))
+            self.plans[key] = SplitPlan(parts, whole)
         return self.plans[key]
 
     def plan_down(self, stride):

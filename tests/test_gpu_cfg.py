@@ -60,7 +60,7 @@ def _plan_key(cm, plan):
 
 
 def _oracle_nbr(frame, key):
-    if key[0] == "k3":
+    if key[0] in ("k3", "k3split"):  # a two-pass plan (sparse.SplitPlan) is the same kernel map
         ts = key[1]
         while ts not in frame.maps:
             frame.down(max(frame.maps))
@@ -258,7 +258,7 @@ def test_cfg3_batch64_fullsize_frames(gpu, oracle, cfg2):
             profiling.INSTANCE_LOG = None
         wide = [e for e in log if e[3] >= 32 and e[3] % 4 == 0 and e[4] >= 32]
         assert wide and all(e[1]["fast"] == 1 for e in wide), [e for e in wide if e[1]["fast"] != 1][:3]
-        big = [e for e in log if e[2] == 27 and e[3] >= 384 and e[4] == 384 and e[5] > 500_000]
+        big = [e for e in log if e[2] in (13, 14, 27) and e[3] >= 384 and e[4] == 384 and e[5] > 500_000]  # 13 / 14: passes
         assert big and all(e[0] == "conv_fwd_dual_kernel<64, 32, 4, 3>" for e in big), big[:3]
         assert len(log) > 70  # 61 layers; the widest ones as several ranges
         labels, _ = s_out.slice_argmax(field)

@@ -314,3 +314,52 @@ def test_batch_range_plans_equal_whole_map_launches(gpu, monkeypatch):
     plan = cm.plan_k3(1)
     plan._chunked.clear()
     assert plan.chunks(4 * 64, 4 * 64) is None
+
+
+def test_two_pass_layers_have_the_bits_of_one_launch(gpu, oracle):
+    """sparse.SplitPlan / sv_conv_fwd_acc: a 3x3x3 layer run as two passes over offsets [0, 14) and [14, 27), each with its
+    own row order, the raw accumulators handed over through memory - bit-identical to the single launch and to the
+    oracle, with BN, residual, ReLU, multi-chunk Cin with a partial last chunk, other split points, and a forced tile shape
+    on every pass (so that the hand-over is exercised on the generic, the FAST and the dual-body instances)."""
+    import os
+
+    import mrcc_amd
+    from mrcc_amd import MinkowskiEngine as ME
+    from mrcc_amd import nn as svnn
+    from mrcc_amd.sparse import SplitPlan
+
+    pts, rgb, _ = mrcc_amd.synth.gen_room(60_000, 1.3, 9)
+    c4 = np.concatenate([np.zeros((len(pts), 1), np.float32), pts * np.float32(50)], axis=1)
+    x = ME.TensorField(torch.from_numpy(rgb), torch.from_numpy(c4), device=gpu).sparse()
+    cm = x.coordinate_manager
+    V = cm.stride_map(1).V
+    whole = cm.plan_k3(1)
+    frame = oracle.Frame(oracle.voxelize(c4)["coords"])
+    nbr = frame.k3(1)
+    rng = np.random.default_rng(11)
+    t = lambda a: torch.from_numpy(a).to(gpu)
+    for cin, cout, split, force in ((416, 384, 14, None), (200, 384, 13, "64,4,3"), (96, 192, 9, "16,4,3"), (35, 50, 20, None),
+                                    (384, 384, 14, "32,4,3")):
+        f = rng.normal(size=(V, cin)).astype(np.float32)
+        W = (rng.normal(size=(27, cin, cout)) * np.sqrt(2.0 / (27 * cout))).astype(np.float32)
+        sc = rng.uniform(0.5, 1.5, size=cout).astype(np.float32)
+        sh = rng.normal(size=cout).astype(np.float32)
+        res = rng.normal(size=(V, cout)).astype(np.float32)
+        one = svnn.conv_forward(t(f), t(W), whole, V, t(sc), t(sh), t(res), 1)
+        sp = cm.plan_k3_split(1, split)
+        assert isinstance(sp, SplitPlan) and [(a, b) for a, b, _ in sp.parts] == [(0, split), (split, 27)]
+        if force:
+            os.environ["SV_CONV_FORCE"] = force
+        try:
+            two = svnn.conv_forward(t(f), t(W), sp, V, t(sc), t(sh), t(res), 1)
+        finally:
+            os.environ.pop("SV_CONV_FORCE", None)
+        assert torch.equal(one, two), (cin, cout, split, force, (one - two).abs().max().item())
+        if cin <= 200:  # the oracle once per shape class (seconds)
+            want = oracle.conv(f, W, nbr, V, sc, sh, res, oracle.ACT_RELU)
+            assert np.array_equal(two.cpu().numpy(), want)
+    # row-slot efficiency really is what the split is for: fewer active (sub-tile, offset) slots than the single plan
+    def slots(pl):
+        return int(sum(bin(int(v) & 0xFFFFFFFF).count("1") for v in pl.submask.cpu().numpy().reshape(-1)))
+    sp = cm.plan_k3_split(1, 14)
+    assert sum(slots(pl) for _, _, pl in sp.parts) < 0.95 * slots(whole)

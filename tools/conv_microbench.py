@@ -22,6 +22,7 @@ ap.add_argument("--iters", type=int, default=200)  # long enough for the clocks 
 ap.add_argument("--points", type=int, default=200000)
 ap.add_argument("--kind", default="k3")
 ap.add_argument("--cube", type=int, default=0, help="solid cube of this edge length (voxels) instead of the room cloud")
+ap.add_argument("--split", default="0", help="run the 3x3x3 layer as passes over offset ranges: 14 -> [0,14) [14,27); 9,18 -> three")
 args = ap.parse_args()
 
 dev = torch.device("cuda:0")
@@ -48,10 +49,15 @@ torch.manual_seed(0)
 feats = torch.randn(V_in, args.cin, device=dev)
 W = torch.randn(K, args.cin, args.cout, device=dev) * 0.05
 P = plan.num_pairs() if plan is not None else V
-sub = plan.submask.cpu().numpy() if plan is not None else None
-if sub is not None:
-    slots = sum(bin(int(v)).count("1") for v in sub.reshape(-1)) * 16
-    print(f"V={V} pairs={P} row-slots={slots} slot-efficiency={P / slots:.3f} tiles={sub.shape[0]}")
+subs = [plan.submask.cpu().numpy()] if plan is not None else []
+cuts = tuple(int(v) for v in args.split.split(",") if int(v))
+if cuts and args.kind == "k3":
+    plan = cm.plan_k3_split(ts, cuts[0] if len(cuts) == 1 else cuts)
+    subs = [pl.submask.cpu().numpy() for _, _, pl in plan.parts]
+if subs:
+    slots = sum(bin(int(v)).count("1") for sub in subs for v in sub.reshape(-1)) * 16
+    print(f"V={V} pairs={P} row-slots={slots} slot-efficiency={P / slots:.3f} tiles={subs[0].shape[0]}"
+          + (f" ({len(subs)} passes)" if len(subs) > 1 else ""))
 for _ in range(2):
     out = svnn.conv_forward(feats, W, plan, V)
 torch.cuda.synchronize()
