@@ -43,7 +43,7 @@ def _parse_split_rules(text):
     return sorted(rules, key=lambda r: -r[0])
 
 
-SPLIT_RULES = _parse_split_rules(_os.environ.get("MRCC_SPLIT_RULES", "60000:14;20000:14"))
+SPLIT_RULES = _parse_split_rules(_os.environ.get("MRCC_SPLIT_RULES", "20000:9,18"))
 SPLIT_MIN_CHANNELS = int(_os.environ.get("MRCC_SPLIT_MIN_CHANNELS", "128"))
 
 
