@@ -951,12 +951,16 @@ def main():
                 groups = tj.get("kernels_by_grid", {}).get(name)
                 if groups:  # the launches of this layer shape: the group whose grid is closest to this layer's
                     rows = warm_by_layer[dominant_layer]["rows"] / warm_by_layer[dominant_layer]["launches"]
-                    want_grid = rows / 64.0 * 2.3  # 64-row tiles x 2 column halves + 15 % of the tiles at half height
+                    want_grid = rows / 64.0 * 2.3  # 64-row tiles x 2 column halves + 15 % of the tiles at half height (per pass)
                     tr = min(groups, key=lambda g: abs(math.log(g["grid_workgroups"] / want_grid)))
                 if tr:
-                    alg_gb = warm_by_layer[dominant_layer]["bytes"] / warm_by_layer[dominant_layer]["launches"] / 1e9
+                    wl = warm_by_layer[dominant_layer]
+                    alg_gb = wl["bytes"] / wl["launches"] / 1e9
+                    passes = wl["kernel_launches"] / wl["launches"]  # offset-range passes: kernel launches per layer
+                    tr = dict(tr, traffic_GB_per_launch=round(tr["traffic_GB_per_launch"] * passes, 4))
+                    roofline["kernel_launches_per_layer"] = passes
                     roofline["traffic"] = tr["traffic_GB_per_launch"]
-                    roofline["traffic_unit"] = "GB per launch (PMC, calibrated)"
+                    roofline["traffic_unit"] = "GB per layer = per pass (PMC, calibrated) x passes"
                     roofline["traffic_source"] = {"file": "profiles/" + os.path.basename(tfile),
                                                   "collected_at_commit": tj.get("commit", "unknown")}
                     roofline["algorithmic_GB_per_launch"] = round(alg_gb, 4)

@@ -98,7 +98,8 @@ def _conv_forward_split(feats, weight3, plan, V_out, scale, shift, residual, act
     finally:
         profiling.TIMER = held
     if t0 is not None:
-        timer.stop(t0, _lib.conv_last_instance()[0], K, Cin, Cout, V_out, plan.pairs_device(), level=plan.out_stride)
+        timer.stop(t0, _lib.conv_last_instance()[0], K, Cin, Cout, V_out, plan.pairs_device(), level=plan.out_stride,
+                   passes=len(plan.parts))
     return out
 
 

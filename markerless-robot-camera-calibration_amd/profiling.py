@@ -108,10 +108,10 @@ class KernelTimer:
         e.record()
         return e
 
-    def stop(self, start_evt, kernel, K, Cin, Cout, V_out, pairs_dev, level=None):
+    def stop(self, start_evt, kernel, K, Cin, Cout, V_out, pairs_dev, level=None, passes=1):
         e = self._event()
         e.record()
-        self.records.append((kernel, K, Cin, Cout, V_out, pairs_dev, start_evt, e, self._first_of_frame, level))
+        self.records.append((kernel, K, Cin, Cout, V_out, pairs_dev, start_evt, e, self._first_of_frame, level, passes))
         self._first_of_frame = False
 
     def frame_boundary(self):
@@ -137,15 +137,16 @@ class KernelTimer:
         layer_key() instead of the kernel name alone (an instance that serves several layer shapes has no one
         "flops per launch")."""
         out = {}
-        for kernel, K, Cin, Cout, V_out, pairs_dev, s, e, first, level in self.records:
+        for kernel, K, Cin, Cout, V_out, pairs_dev, s, e, first, level, passes in self.records:
             if first:
                 continue
             P = int(pairs_dev.item()) if pairs_dev is not None else V_out
             ms = s.elapsed_time(e)
             key = self.layer_key(kernel, K, Cin, Cout, V_out, level) if by_layer else kernel
-            d = out.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "rows": 0.0})
+            d = out.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "rows": 0.0, "kernel_launches": 0})
             d["rows"] += V_out
-            d["launches"] += 1
+            d["launches"] += 1  # layers; a layer run as offset-range passes is several kernel launches
+            d["kernel_launches"] += passes
             d["ms"] += ms
             d["flops"] += 2.0 * P * Cin * Cout
             d["bytes"] += P * (4.0 * Cin + 8) + 4.0 * V_out * Cout + 4.0 * K * Cin * Cout

@@ -15,7 +15,7 @@ def per_kernel(prefix, counter):
             if r["Counter_Name"] == counter and ("conv_fwd_kernel" in r["Kernel_Name"] or "conv_fwd_dual_kernel" in r["Kernel_Name"] or "linear_narrow_kernel" in r["Kernel_Name"]):
                 acc[r["Kernel_Name"].split("(")[0].replace("void sv::", "")].append(float(r["Counter_Value"]))
     return acc
-V = 2_000_000
+V = 1_300_000
 known_read = V * 384 * 4 + 384 * 192 * 4
 known_write = V * 192 * 4
 def per_kernel_grid(prefix, counter):

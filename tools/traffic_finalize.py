@@ -35,7 +35,7 @@ out = {
     "calibration": {"kernel": fold(cal_name), "known_read_bytes": known["read_bytes"],
                     "known_write_bytes": known["write_bytes"], "FETCH_SIZE_KB": cal["FETCH_SIZE"],
                     "WRITE_SIZE_KB": cal["WRITE_SIZE"], "fetch_factor": round(ff, 4), "write_factor": round(wf, 4),
-                    "note": "dense 1x1 launch reading 3.07 GB / writing 1.54 GB exactly once (tools/traffic_calib.py); "
+                    "note": "dense 1x1 launch reading 2.0 GB / writing 1.0 GB exactly once (tools/traffic_calib.py); "
                             "FETCH_SIZE * 1024 under-reports the 16 B/lane row gathers by fetch_factor, WRITE_SIZE is exact"},
     "kernels": {},
 }
