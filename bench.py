@@ -676,7 +676,7 @@ def engine_block(device):
         pool = [mrcc_amd.synth.gen_room(POINTS, ROOM, sd)[:2] for sd in range(4)]
         frames = [pool[i % 4] for i in range(32)]
         for i in range(3):  # the allocator re-grows its pools after the previous block's empty_cache()
-            ref = eng.predict_segmentation(*pool[(i + 2) % 4])
+            ref = eng.predict_segmentation(*pool[(i + 3) % 4])  # the last one is pool[1], compared below
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(6):
