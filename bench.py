@@ -934,8 +934,13 @@ def main():
                                          "(s<tensor stride>: s1 = level 0)",
                 "bound": "mfma", "achieved": round(tflops, 3), "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                # a layer run as offset-range passes is several kernel launches behind ONE event interval: "launch" below =
+                # layer; the per-kernel-launch figures (what a rocprofv3 kernel trace lists) are beside it
                 "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                 "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
+                "kernel_launches": d["kernel_launches"],
+                "avg_kernel_launch_ms": round(d["ms"] / max(d["kernel_launches"], 1), 4),
+                "algorithmic_gflop_per_kernel_launch": round(d["flops"] / max(d["kernel_launches"], 1) / 1e9, 3),
                 "compute_streams": args.streams,
                 "note": "achieved / frac = per-launch HIP-event intervals INSIDE the timed regions, where a launch shares "
                         "the chip with the other frames' kernels; `isolated` = the same launches alone on the GPU; "
@@ -979,7 +984,8 @@ def main():
             # the same instance with nothing else on the GPU (warm-up pass on one compute stream): with several compute
             # streams the timed-region duration of a launch includes the time it shares the CUs with the other frame
             roofline["isolated"] = {"achieved": round(iso_tf, 3), "frac": round(iso_tf / PEAK_F32_MFMA_TFLOPS, 4),
-                                    "avg_launch_ms": round(iso["ms"] / iso["launches"], 4)}
+                                    "avg_launch_ms": round(iso["ms"] / iso["launches"], 4),
+                                    "avg_kernel_launch_ms": round(iso["ms"] / max(iso["kernel_launches"], 1), 4)}
             # the whole step against the matrix peak: every conv launch's algorithmic flops (2 P Cin Cout, warm-up pass,
             # where all of them are counted) over the median ms_per_step of this rank's timed regions
             e2e = gflop_step / (elapsed / args.steps * 1e3) if elapsed > 0 else 0.0  # GFLOP / ms = TFLOP/s
