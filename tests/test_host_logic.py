@@ -174,3 +174,23 @@ def test_kernel_offset_permutation_is_applied_when_loading():
             dst.load_state_dict(sd)
         finally:
             svnn.KERNEL_OFFSET_PERMUTATION = None
+
+
+def test_split_rules_parse_and_apply():
+    """nn.SPLIT_RULES ("min_rows:cut[,cut...];..."): which 3x3x3 layers run as offset-range passes (sparse.SplitPlan)."""
+    from mrcc_amd import nn as svnn
+
+    rules = svnn._parse_split_rules("20000:9,18;60000:7,14,20;5000:14;")
+    assert rules == [(60000, (7, 14, 20)), (20000, (9, 18)), (5000, 14)]  # biggest map first; one cut -> an int
+    assert svnn._parse_split_rules("") == []
+    old = svnn.SPLIT_RULES
+    try:
+        svnn.SPLIT_RULES = rules
+        assert svnn.split_points_for(88_113) == (7, 14, 20) and svnn.split_points_for(26_552) == (9, 18)
+        assert svnn.split_points_for(6_849) == 14 and svnn.split_points_for(1_732) is None
+        svnn.SPLIT_RULES = []
+        assert svnn.split_points_for(10 ** 9) is None
+    finally:
+        svnn.SPLIT_RULES = old
+    # the default: three passes on maps of at least 20 000 voxels (tools/ab_split.sh)
+    assert svnn._parse_split_rules("20000:9,18") == [(20000, (9, 18))]
