@@ -8,6 +8,7 @@
 Reference call sites: app/inference_engine.py:405-417,446-454,540-551; test_segmentation.py:62-72;
 train_segmentation.py:78; data/alivev2.py:363.  Everything numeric is a libsvhip.so call (include/sv_hip.h).
 """
+import weakref
 from ctypes import c_float, c_int, c_int64, c_size_t
 from enum import Enum
 
@@ -98,8 +99,8 @@ class ConvPlan:
         the range's first row - the same (offset, channel) chain per output element, i.e. the same bits, on the FAST
         instances.  Returns [(plan, in0, in1, out0, out1)] or None when the whole map fits (or cannot be split: one
         frame alone beyond the extent, which then takes the guarded 64-bit form)."""
-        cm = self.cm
-        if cm is None or self.raw is None:
+        cm = self.cm() if self.cm is not None else None  # weak reference: a plan must not keep its manager (and through it
+        if cm is None or self.raw is None:               # every tensor of the frame) alive in a reference cycle
             return None
         V_in = cm.stride_map(self.in_stride).V
         if V_in * in_row_bytes < BUF_LIMIT and self.V_out * out_row_bytes < BUF_LIMIT:
@@ -170,7 +171,7 @@ class CoordinateManager:
         self.phase_hook = None  # set per frame by app/pipeline.py FramePipeline.run (see model/backbone/minkunet.py)
 
     def _own(self, plan, nbr, ld, mask, in_stride, out_stride):
-        plan.cm, plan.raw, plan.in_stride, plan.out_stride = self, (nbr, ld, mask), in_stride, out_stride
+        plan.cm, plan.raw, plan.in_stride, plan.out_stride = weakref.ref(self), (nbr, ld, mask), in_stride, out_stride
         return plan
 
     # ---- coordinate maps -------------------------------------------------------------------
