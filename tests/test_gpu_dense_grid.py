@@ -132,10 +132,17 @@ def _nets():
             "seg_head": lambda: _classification_head(MinkUNet14A, lambda: 3, "SegHead14A")(3, num_classes=3)}
 
 
-@pytest.mark.parametrize("which", ["minkunet14a", "bottleneck_unet", "seg_head"])
-def test_unet_matches_dense_grid_float64(gpu, which):
+@pytest.mark.parametrize("which", ["minkunet14a", "bottleneck_unet", "seg_head", "minkunet14a as offset-range passes"])
+def test_unet_matches_dense_grid_float64(gpu, which, monkeypatch):
     from mrcc_amd import MinkowskiEngine as ME
+    from mrcc_amd import nn as svnn
 
+    if which.endswith("passes"):
+        # every 3x3x3 layer with >= 16 channels on every level as three offset-range passes (sparse.SplitPlan), whatever the
+        # map's size: the independent dense network then also pins the accumulator hand-over between the passes
+        monkeypatch.setattr(svnn, "SPLIT_RULES", [(0, (9, 18))])
+        monkeypatch.setattr(svnn, "SPLIT_MIN_CHANNELS", 16)
+        which = "minkunet14a"
     torch.manual_seed(21)
     net = _nets()[which]()
     n_out = 3 if which == "seg_head" else 20
@@ -158,6 +165,8 @@ def test_unet_matches_dense_grid_float64(gpu, which):
         x = ME.SparseTensor(torch.from_numpy(np.concatenate(feats)), coordinates=torch.from_numpy(coords4).int(),
                             device=gpu)
         out = net(x)
+    if svnn.SPLIT_RULES and svnn.SPLIT_RULES[0][0] == 0:
+        assert any(k[0] == "k3split" for k in x.coordinate_manager.plans), "the passes were not used"
     got = out.F.cpu().numpy().astype(np.float64)
     oc = out.C.cpu().numpy().astype(np.int64)  # (batch, x, y, z) of every output row
     # ---- the dense side: [N, C, Z, Y, X]
