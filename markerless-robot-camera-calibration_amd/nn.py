@@ -83,33 +83,30 @@ def _conv_forward_split(feats, weight3, plan, V_out, scale, shift, residual, act
         kname = profiling.conv_kernel_config(Cout, plan.Vpad, Cin, plan.parts[-1][1] - plan.parts[-1][0])
         if timer.want(kname):
             t0 = timer.start()
-    held, profiling.TIMER = profiling.TIMER, None  # the passes are ONE layer for the per-kernel table
-    try:
-        acc = None
-        for i, (k0, k1, sub) in enumerate(plan.parts):
-            last = i == len(plan.parts) - 1
-            w = weight3[k0:k1]
-            if last:
-                _conv_forward_one(feats, w, sub, V_out, scale, shift, residual, act, slope, out, acc)
-            else:
-                nxt = torch.empty((V_out, Cout), dtype=torch.float32, device=feats.device)
-                _conv_forward_one(feats, w, sub, V_out, None, None, None, SV_ACT_NONE, slope, nxt, acc)
-                acc = nxt
-    finally:
-        profiling.TIMER = held
+    if not weight3.is_contiguous():
+        weight3 = weight3.contiguous()  # a pass takes the block W[k0:k1] by pointer
+    acc = None
+    for i, (k0, k1, sub) in enumerate(plan.parts):  # timed=False: the passes are ONE layer for the per-kernel table
+        w = weight3[k0:k1]
+        if i == len(plan.parts) - 1:
+            _conv_forward_one(feats, w, sub, V_out, scale, shift, residual, act, slope, out, acc, timed=False)
+        else:
+            nxt = torch.empty((V_out, Cout), dtype=torch.float32, device=feats.device)
+            _conv_forward_one(feats, w, sub, V_out, None, None, None, SV_ACT_NONE, slope, nxt, acc, timed=False)
+            acc = nxt
     if t0 is not None:
         timer.stop(t0, _lib.conv_last_instance()[0], K, Cin, Cout, V_out, plan.pairs_device(), level=plan.out_stride,
                    passes=len(plan.parts))
     return out
 
 
-def _conv_forward_one(feats, weight3, plan, V_out, scale, shift, residual, act, slope, out, acc_init):
+def _conv_forward_one(feats, weight3, plan, V_out, scale, shift, residual, act, slope, out, acc_init, timed=True):
     K, Cin, Cout = weight3.shape
     if plan is None:
         Vpad = (max(V_out, 1) + _lib.SV_TILE_ROWS - 1) // _lib.SV_TILE_ROWS * _lib.SV_TILE_ROWS
     else:
         Vpad = plan.Vpad
-    timer = profiling.TIMER
+    timer = profiling.TIMER if timed else None
     t0 = None
     if timer is not None:
         kname = profiling.conv_kernel_config(Cout, Vpad, Cin, K)
