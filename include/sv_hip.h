@@ -61,8 +61,11 @@ typedef void* sv_stream_t;
 const char* sv_last_error(void);
 /* 2: sv_conv_fwd takes V_in (rows of `in`); sv_single_linkage_roots / sv_select_equal added
  * 3: sv_plan_build takes nbr_base (plans of a batch range of a kernel map); sv_key_point_predictions,
- *    sv_conv_last_instance and sv_conv_fwd_acc (offset-range passes of one layer) added */
-#define SV_ABI_VERSION 3
+ *    sv_conv_last_instance and sv_conv_fwd_acc (offset-range passes of one layer) added
+ * 4: sv_conv_set_dispatch (per-thread dispatch thresholds: one frame alone vs frames overlapped), the frame composites
+ *    sv_frame_maps / sv_frame_plans (a frame's coordinate work as two host calls), sv_topk_mean_rows (get_pred_center),
+ *    sv_key_point_predictions_batched */
+#define SV_ABI_VERSION 4
 int sv_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -136,6 +139,53 @@ int sv_plan_build(const int32_t* nbr, int64_t ld, const uint32_t* mask, int K, i
                   int64_t Vpad, sv_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Frame composites: the coordinate work of ONE frame as two host calls (the reference reaches all of it implicitly through
+ * ME.TensorField(...).sparse(), app/inference_engine.py:405-415, and the ME.MinkowskiConvolution calls of
+ * model/backbone/minkunet.py:125-183; its consumer calls InferenceEngine.predict once per frame, app/main.py:432-456, so the
+ * host time of ~200 launches behind ~120 calls is frame latency).  Same kernels, same array contents as the piecewise entry
+ * points above.
+ *
+ * sv_frame_maps: voxelise (as sv_voxelize) + `levels` stride-2 maps (as sv_stride_map).  The level sizes are read back
+ *   inside the call through `counters_host` (PINNED host memory, 4 * (levels + 2) int32): the only host synchronisations of
+ *   a frame's coordinate work, each waiting for this call's own kernels on `stream`.  Outputs are carved from `arena`
+ *   (sv_frame_maps_arena_bytes: worst case V_l <= N); `scratch` (sv_frame_maps_scratch_bytes) is free again on return.
+ *   layout (host int64[8 + 6 * (levels + 1)]): [0] arena bytes used, [1] N, [2] levels, [3] offset of inverse int64[N],
+ *   [4] order int32[N], [5] seg_start int32[V_0 + 1], [6] points outside the key range (then SV_ERR_RANGE), then per level l
+ *   six entries: V_l, offset of keys uint64[V_l], vcoords int32[V_l][4], parent int32[V_l] (row of each voxel in level
+ *   l + 1; -1 at the last level), child_start int32[V_{l+1} + 1] (-1 at the last level), 0.
+ * sv_frame_plans: hash tables, kernel maps and conv plans of levels 0..levels; no synchronisation.  flags select what is
+ *   built: SV_FRAME_K3 (27-offset map + plan per level), SV_FRAME_DOWN / SV_FRAME_UP (the kernel_size 2 stride 2 maps
+ *   between levels l and l + 1 and their plans), SV_FRAME_SPLIT (offset-range plans: split_cuts[l][SV_FRAME_MAX_CUTS] holds
+ *   level l's ascending split points, 0-terminated; they need the level's 27-offset map - built by SV_FRAME_K3 in the same
+ *   call or passed in k3_nbr[l] / k3_mask[l], so that a caller can build them in a second call while the encoder runs).
+ *   keys / coords / parent: per-level device pointers (parent[l] as in sv_frame_maps).  layout (host int64[16 * (1 +
+ *   max_records)]): [0] arena bytes used, [1] number of records; record r at 16 * (1 + r): kind (SV_FRAME_REC_*), level, k0,
+ *   k1, offset of the raw map int32[K][ld] (hash: of the table values; -1: rows k0..k1 of the caller's k3_nbr), of its mask
+ *   (split: the range's mask), of perm, nbr_s, submask, tile_order, V_out, Vpad, K, ld, offset of the hash keys, capacity.
+ * ------------------------------------------------------------------------------------------- */
+#define SV_FRAME_MAX_LEVELS 8
+#define SV_FRAME_MAX_CUTS 4
+#define SV_FRAME_K3 1
+#define SV_FRAME_DOWN 2
+#define SV_FRAME_UP 4
+#define SV_FRAME_SPLIT 8
+#define SV_FRAME_RECORD 16
+#define SV_FRAME_REC_HASH 1
+#define SV_FRAME_REC_K3 2
+#define SV_FRAME_REC_DOWN 3
+#define SV_FRAME_REC_UP 4
+#define SV_FRAME_REC_SPLIT 5
+size_t sv_frame_maps_arena_bytes(int64_t N, int levels);
+size_t sv_frame_maps_scratch_bytes(int64_t N);
+int sv_frame_maps(const void* coords4, int coords_are_int, int64_t N, int levels, void* arena, size_t arena_bytes, void* scratch,
+                  size_t scratch_bytes, int32_t* counters_host, int64_t* layout, sv_stream_t stream);
+size_t sv_frame_plans_arena_bytes(const int64_t* V, int levels, int flags, const int32_t* split_cuts);
+size_t sv_frame_plans_scratch_bytes(const int64_t* V, int levels);
+int sv_frame_plans(const void* const* keys, const void* const* coords, const void* const* parent, const int64_t* V, int levels,
+                   int flags, const int32_t* split_cuts, const void* const* k3_nbr, const void* const* k3_mask, void* arena,
+                   size_t arena_bytes, void* scratch, size_t scratch_bytes, int64_t* layout, int max_records, sv_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * A3/A5  sparse convolution, output stationary, fp32 MFMA, fused epilogue
  *   (replaces ME.MinkowskiConvolution / ConvolutionTranspose / Linear + MinkowskiBatchNorm(eval) +
  *    residual add + ReLU/LeakyReLU: model/backbone/minkunet.py:125-187, resnet.py:95-127,
@@ -176,6 +226,14 @@ int sv_conv_fwd_acc(const float* in, int64_t V_in, int64_t in_ld, int Cin, const
  * form; a tensor beyond its 2 GB extent, a misaligned plan or an odd channel count takes the guarded form).  Tests and the
  * bench's per-kernel table read it back instead of re-deriving the dispatch. */
 const char* sv_conv_last_instance(void);
+/* Dispatch thresholds of the calling thread's later sv_conv_fwd calls.  The instance lists were measured one launch at a
+ * time; inside a multi-stream frame pipeline taller tiles win earlier (their launch tails are filled by the neighbour
+ * frames' kernels), so the library default scales every "chosen from N workgroups" threshold by 0.3.  A caller that runs
+ * ONE frame at a time (the reference's consumer: InferenceEngine.predict per frame, app/main.py:432-456) sets
+ * want_scale = 1.  tail_fraction = share of the plan tiles that chip-filling launches run as half-height tiles.
+ * A negative value restores the library default (environment SV_CONV_WANT_SCALE / SV_CONV_TAIL).  Results never depend on
+ * the instance (one fma chain per output element in every one of them). */
+int sv_conv_set_dispatch(double want_scale, double tail_fraction);
 
 /* Stand-alone BN(eval)/bias + residual + activation on feature rows, same arithmetic as the conv epilogue:
  *   out[v][c] = act( fmaf(in[v][c], scale[c], shift[c]) + residual[v][c] )

@@ -10,7 +10,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 3  # SV_ABI_VERSION of include/sv_hip.h
+ABI_VERSION = 4  # SV_ABI_VERSION of include/sv_hip.h
 LIB_PATH = os.environ.get("SVHIP_LIB") or os.path.join(_HERE, "libsvhip.so")  # SVHIP_LIB: kernel A/B experiments
 
 SV_ACT_NONE, SV_ACT_RELU, SV_ACT_LEAKY_RELU = 0, 1, 2
@@ -20,6 +20,9 @@ SV_TILE_ROWS = 128
 SV_COORD_BIAS = 1 << 17
 SV_COORD_BITS = 18
 SV_MAX_BATCH = 1024
+SV_FRAME_MAX_LEVELS, SV_FRAME_MAX_CUTS, SV_FRAME_RECORD = 8, 4, 16
+SV_FRAME_K3, SV_FRAME_DOWN, SV_FRAME_UP, SV_FRAME_SPLIT = 1, 2, 4, 8
+SV_FRAME_REC_HASH, SV_FRAME_REC_K3, SV_FRAME_REC_DOWN, SV_FRAME_REC_UP, SV_FRAME_REC_SPLIT = 1, 2, 3, 4, 5
 
 
 class SvHipError(RuntimeError):
@@ -53,6 +56,13 @@ SIGNATURES = {
          c_float, _P, c_int64, _P],
     ),
     "sv_conv_last_instance": (c_char_p, []),
+    "sv_conv_set_dispatch": (c_int, [c_double, c_double]),
+    "sv_frame_maps_arena_bytes": (c_size_t, [c_int64, c_int]),
+    "sv_frame_maps_scratch_bytes": (c_size_t, [c_int64]),
+    "sv_frame_maps": (c_int, [_P, c_int, c_int64, c_int, _P, c_size_t, _P, c_size_t, _P, _P, _P]),
+    "sv_frame_plans_arena_bytes": (c_size_t, [_P, c_int, c_int, _P]),
+    "sv_frame_plans_scratch_bytes": (c_size_t, [_P, c_int]),
+    "sv_frame_plans": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, c_size_t, _P, c_size_t, _P, c_int, _P]),
     "sv_affine_act": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, _P, c_int64, c_int, c_float, _P, c_int64, _P]),
     "sv_col_stats_workspace_bytes": (c_size_t, [c_int64]),
     "sv_col_stats": (c_int, [_P, c_int64, c_int64, c_int, _P, _P, c_size_t, _P, _P, _P, _P, _P]),
@@ -130,6 +140,20 @@ def conv_last_instance():
     raw = load().sv_conv_last_instance().decode()
     name, _, flags = raw.partition("|")
     return name, {k: int(v) for k, v in (kv.split("=") for kv in flags.split(",") if kv)}
+
+
+class conv_dispatch:
+    """`with conv_dispatch(want_scale):` - dispatch thresholds of this thread's sv_conv_fwd calls inside the block
+    (sv_conv_set_dispatch; 1.0 = one frame alone on the GPU), library defaults restored afterwards."""
+
+    def __init__(self, want_scale, tail_fraction=-1.0):
+        self.args = (c_double(want_scale), c_double(tail_fraction))
+
+    def __enter__(self):
+        call("sv_conv_set_dispatch", *self.args)
+
+    def __exit__(self, *exc):
+        call("sv_conv_set_dispatch", c_double(-1.0), c_double(-1.0))
 
 
 def require_cuda(t, what="tensor"):

@@ -137,14 +137,21 @@ class InferenceEngine:
         return self._segmentation_model(x).slice_argmax(field, with_conf=False)[0]
 
     def predict_segmentation(self, points, rgb):
-        cfg = self._config
-        # F8a: the reference centres the points and then voxelises the RAW ones (:396-408)
-        with torch.no_grad():
-            field = self._field(points, rgb, cfg.INFERENCE.SEGMENTATION.scale)
-            label = self._segment(field.sparse(), field)
-            xyz = torch.as_tensor(np.asarray(points), dtype=torch.float32).to(self.device)
-            label = self._largest_ee_cluster_rule(label, xyz)
-        return label.cpu().numpy()
+        """app/inference_engine.py:395-435.  One frame start to finish, as the reference's consumer calls it (one
+        predict() per frame, app/main.py:432-456): pinned staging and asynchronous copies, the frame's coordinate work as
+        two libsvhip calls on a prep stream (its size read-backs wait for nothing but that work), the network enqueued
+        behind it without a host synchronisation, the decoder's offset-range plans built while the encoder runs
+        (app/pipeline.py FramePipeline one_frame).  F8a: the reference centres the points and then voxelises the RAW
+        ones (:396-408)."""
+        from .pipeline import HostFrameStream
+
+        scale = self._config.INFERENCE.SEGMENTATION.scale
+        st = self.__dict__.get("_one_frame_stream")
+        if st is None or st.scale != scale:
+            st = HostFrameStream(self.device, scale, self._segment, self._largest_ee_cluster_rule, compute_streams=1,
+                                 one_frame=True)
+            self._one_frame_stream = st
+        return st.run_one(points, rgb)
 
     def predict_segmentation_stream(self, frames, compute_streams=3):
         """Streaming form of predict_segmentation for a sequence of frames (the reference's consumer is the per-frame

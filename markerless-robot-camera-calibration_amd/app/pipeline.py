@@ -28,28 +28,31 @@ class PreparedFrame:
 
 def build_unet_plans(cm, levels=4):
     """Everything a MinkUNet-shaped graph will ask the coordinate manager for (model/backbone/minkunet.py:125-183):
-    3x3x3 maps at strides 1..2^levels, stride-2 down maps and transposed up maps between neighbouring levels."""
-    for l in range(levels):
-        ts = 1 << l
-        cm.plan_k3(ts)
-        cm.plan_down(ts)
-    cm.plan_k3(1 << levels)
-    for l in range(levels, 0, -1):
-        cm.plan_up(1 << l)
-    # the two-pass plans of the wide decoder layers on big levels (nn.SPLIT_MIN_ROWS) are built here, on the prep stream
-    from .. import nn as svnn
-
-    for l in range(levels):
-        cuts = svnn.split_points_for(cm.stride_map(1 << l).V)
-        if cuts is not None:
-            cm.plan_k3_split(1 << l, cuts)
+    3x3x3 maps at strides 1..2^levels, stride-2 down maps and transposed up maps between neighbouring levels, and the
+    offset-range plans of the wide decoder layers on big levels - one sv_frame_plans call (the stride maps it needs come
+    from TensorField.sparse(pyramid_levels=levels), or are built here one by one)."""
+    cm.build_plans(levels)
 
 
 class FramePipeline:
-    def __init__(self, device, levels=4, encoder_only=False, compute_streams=1, stagger_level0=None):
+    def __init__(self, device, levels=4, encoder_only=False, compute_streams=1, stagger_level0=None, one_frame=False):
         self.device = torch.device(device)
         self.levels = levels
         self.encoder_only = encoder_only
+        # one_frame: the caller runs ONE frame at a time and waits for it (InferenceEngine.predict per frame, the reference's
+        # consumer loop app/main.py:432-456) - nothing else fills the GPU, so (i) the network starts as soon as the encoder's
+        # plans exist and the offset-range plans of the decoder are built on the prep stream meanwhile, (ii) only level 0 runs
+        # as offset-range passes (nn.SPLIT_RULES_ONE_FRAME) and (iii) the conv dispatch uses its one-launch-at-a-time
+        # thresholds (sv_conv_set_dispatch(1.0): short tiles on the small levels, whose tails nobody would fill)
+        self.one_frame = one_frame
+        if one_frame:
+            from .. import nn as svnn
+
+            self.split_rules = svnn.SPLIT_RULES_ONE_FRAME
+            self.want_scale = float(os.environ.get("MRCC_ONE_FRAME_WANT_SCALE", "1.0"))
+        else:
+            self.split_rules = None
+            self.want_scale = None
         # the prep stream's ~150 small kernels per frame must not queue behind thousands of conv workgroups: the host
         # blocks on their size read-backs, and a late prepare() starves a compute stream (high priority = -1)
         prio = int(os.environ.get("MRCC_PREP_PRIORITY", "-1"))
@@ -76,17 +79,24 @@ class FramePipeline:
             field = ME.TensorField(features=feats, coordinates=coords4,
                                    quantization_mode=ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE,
                                    minkowski_algorithm=ME.MinkowskiAlgorithm.SPEED_OPTIMIZED, device=self.device)
-            x = field.sparse()
+            x = field.sparse(pyramid_levels=self.levels)  # voxelise + the stride-2 maps: one host call, sizes read back once
             cm = x.coordinate_manager
-            if self.encoder_only:
-                for l in range(self.levels):
-                    cm.plan_k3(1 << l)
-                    cm.plan_down(1 << l)
-                cm.plan_k3(1 << self.levels)
-            else:
-                build_unet_plans(cm, self.levels)
+            cm.split_rules = self.split_rules
             ready = torch.cuda.Event()
-            ready.record(self.prep_stream)
+            if self.encoder_only:
+                cm.build_plans(self.levels, up=False, split=False)
+                ready.record(self.prep_stream)
+            elif self.one_frame:
+                cm.build_plans(self.levels, split=False)
+                ready.record(self.prep_stream)
+                # the decoder's offset-range plans: built while the compute stream already runs the encoder; the first layer
+                # that uses one waits for this event (nn._ConvBase._plan)
+                cm.build_plans(self.levels, k3=False, down=False, up=False, split=True)
+                cm.split_ready = torch.cuda.Event()
+                cm.split_ready.record(self.prep_stream)
+            else:
+                cm.build_plans(self.levels)
+                ready.record(self.prep_stream)
         return PreparedFrame(field, x, ready, tag)
 
     def run(self, prepared, fn):
@@ -105,7 +115,13 @@ class FramePipeline:
         cm.phase_hook = self._phase_hook if (self.stagger_level0 and self.compute_streams and not self.single) else None
         with torch.cuda.stream(compute):
             try:
-                out = fn(prepared.x, prepared.field)
+                if self.want_scale is not None:
+                    from .. import _lib
+
+                    with _lib.conv_dispatch(self.want_scale):
+                        out = fn(prepared.x, prepared.field)
+                else:
+                    out = fn(prepared.x, prepared.field)
             finally:
                 cm.phase_hook = None
         prepared.done = torch.cuda.Event()
@@ -162,11 +178,13 @@ class HostFrameStream:
     into pinned memory run on that frame's stream while LATER frames compute.  Results come back in input order and are
     bit-identical to the synchronous path: the same kernels run on the same data, only their interleaving changes."""
 
-    def __init__(self, device, scale, stage, finish=None, levels=4, compute_streams=3, depth=None, stagger_level0=None):
+    def __init__(self, device, scale, stage, finish=None, levels=4, compute_streams=3, depth=None, stagger_level0=None,
+                 one_frame=False):
         self.device = torch.device(device)
         self.scale = scale
         self.stage, self.finish = stage, finish
-        self.pipe = FramePipeline(self.device, levels=levels, compute_streams=compute_streams, stagger_level0=stagger_level0)
+        self.pipe = FramePipeline(self.device, levels=levels, compute_streams=compute_streams, stagger_level0=stagger_level0,
+                                  one_frame=one_frame)
         self.depth = depth or max(2, compute_streams)
         self._slots = [_HostSlot() for _ in range(self.depth + 2)]
         self._n = 0
@@ -185,20 +203,21 @@ class HostFrameStream:
         rgb_t = rgb if torch.is_tensor(rgb) else None
         channels = (rgb_t.shape[1] if rgb_t is not None else np.asarray(rgb).shape[1])
         slot.reserve(n, channels)
+        prep = self.pipe.prep_stream
         np.copyto(slot.pts.numpy()[:n], np.asarray(points), casting="same_kind")  # float64 sources are rounded here
+        with torch.cuda.stream(prep):  # the points are on their way while the colours are staged
+            d_pts = slot.pts[:n].to(self.device, non_blocking=True)
+            coords4 = torch.zeros((n, 4), dtype=torch.float32, device=self.device)
+            torch.mul(d_pts, self.scale, out=coords4[:, 1:])
         if rgb_t is not None:
             slot.rgb[:n].copy_(rgb_t)
         else:
             np.copyto(slot.rgb.numpy()[:n], np.asarray(rgb), casting="same_kind")
-        prep = self.pipe.prep_stream
         t1 = time.perf_counter()
         with torch.cuda.stream(prep):
-            d_pts = slot.pts[:n].to(self.device, non_blocking=True)
             d_rgb = slot.rgb[:n].to(self.device, non_blocking=True)
             slot.uploaded = torch.cuda.Event()
             slot.uploaded.record(prep)
-            coords4 = torch.zeros((n, 4), dtype=torch.float32, device=self.device)
-            torch.mul(d_pts, self.scale, out=coords4[:, 1:])
         out = self.pipe.prepare(coords4, d_rgb, tag=(slot, d_pts, n))
         t2 = time.perf_counter()
         self.host_s["stage"] += t1 - t0
@@ -229,6 +248,15 @@ class HostFrameStream:
         prepared.result = prepared.tag = None
         self.host_s["finalize"] += time.perf_counter() - t0
         return out
+
+    def run_one(self, points, rgb):
+        """One frame, start to finish (the per-frame call of the reference's loop): staged, uploaded and prepared on the prep
+        stream, the network on the compute stream behind it, labels downloaded - nothing is enqueued between a size
+        read-back and the kernels it waits for except this frame's own coordinate work."""
+        with torch.no_grad():
+            cur = self._upload_and_prepare(points, rgb)
+            self._launch(cur)
+            return self._finalize(cur)
 
     def run(self, frames):
         """frames: iterable of (points [N,3], rgb [N,C]) host arrays -> generator of int64 label arrays, in order."""

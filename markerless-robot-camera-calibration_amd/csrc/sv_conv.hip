@@ -70,6 +70,9 @@ constexpr int PLAN_TILE = SV_TILE_ROWS;
 // name of the kernel instance the last sv_conv_fwd call of this thread launched, "name|fast=F,ring=R,full=U" (the names
 // mrcc_amd/profiling.py predicts; sv_conv_last_instance(): tests and the bench's per-kernel records read it back)
 static thread_local char g_last_instance[128] = "";
+// per-thread override of the dispatch thresholds (sv_conv_set_dispatch): < 0 = the library default / environment
+static thread_local double g_want_scale_override = -1.0;
+static thread_local double g_tail_override = -1.0;
 static void note_instance(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -1451,11 +1454,13 @@ static int select_and_launch(const ConvParams& p, hipStream_t stream) {
       getenv("SV_CONV_WANT_SCALE") ? atof(getenv("SV_CONV_WANT_SCALE")) : SV_CONV_WANT_SCALE_DEFAULT;
   // chip-filling 384-wide layers: 64-row tiles, and 32-row tiles for the cheapest plan tiles at the end of the grid
   static const double tail_fraction = getenv("SV_CONV_TAIL") ? atof(getenv("SV_CONV_TAIL")) : SV_CONV_TAIL_DEFAULT;
+  const double ws = g_want_scale_override >= 0.0 ? g_want_scale_override : want_scale;
+  const double tf = g_tail_override >= 0.0 ? g_tail_override : tail_fraction;
   for (int i = 0; i < n; ++i)
-    if ((double)candidate_wgs(list[i], p) >= want_scale * (double)list[i].want) {
+    if ((double)candidate_wgs(list[i], p) >= ws * (double)list[i].want) {
       const Candidate& c = list[i];
-      if (c.tm == 64 && c.wn == 4 && c.nt == 3 && c.cpo == 0 && tail_fraction > 0.0 &&
-          launch_conv_dual<64, 32, 4, 3>(p, stream, tail_fraction) == SV_OK)
+      if (c.tm == 64 && c.wn == 4 && c.nt == 3 && c.cpo == 0 && tf > 0.0 &&
+          launch_conv_dual<64, 32, 4, 3>(p, stream, tf) == SV_OK)
         return SV_OK;
       return launch_candidate(c, p, stream);
     }
@@ -1467,6 +1472,13 @@ static int select_and_launch(const ConvParams& p, hipStream_t stream) {
 using namespace sv;
 
 extern "C" const char* sv_conv_last_instance(void) { return sv::g_last_instance; }
+
+extern "C" int sv_conv_set_dispatch(double want_scale, double tail_fraction) {
+  SV_CHECK_ARG(tail_fraction < 1.0, "tail_fraction must be below 1");
+  sv::g_want_scale_override = want_scale;
+  sv::g_tail_override = tail_fraction;
+  return SV_OK;
+}
 
 extern "C" int sv_conv_fwd(const float* in, int64_t V_in, int64_t in_ld, int Cin, const float* W, int K, int Cout,
                            const int32_t* perm, const int32_t* nbr_s, const uint32_t* submask,

@@ -47,6 +47,11 @@ SPLIT_RULES = _parse_split_rules(_os.environ.get("MRCC_SPLIT_RULES", "20000:9,18
 SPLIT_MIN_CHANNELS = int(_os.environ.get("MRCC_SPLIT_MIN_CHANNELS", "128"))
 
 
+# one frame alone on the GPU (the per-frame InferenceEngine.predict call): level 1's launches are one round of workgroups
+# already and LOSE with three passes when nothing else fills their tails (100.7 -> 95.5 TFLOP/s)
+SPLIT_RULES_ONE_FRAME = _parse_split_rules(_os.environ.get("MRCC_SPLIT_RULES_ONE_FRAME", "50000:9,18"))
+
+
 def split_points_for(rows):
     """split points of the 3x3x3 layers on an output map of `rows` voxels (None = one pass)"""
     for min_rows, cuts in SPLIT_RULES:
@@ -243,8 +248,12 @@ class _ConvBase(nn.Module):
                 return None, ts
             if ks == 3 and st == 1:
                 if self.dilation == 1 and self.in_channels >= SPLIT_MIN_CHANNELS and self.out_channels >= SPLIT_MIN_CHANNELS:
-                    cuts = split_points_for(cm.stride_map(ts).V)
+                    cuts = cm.split_cuts_for(cm.stride_map(ts).V)  # the frame's own rules, else SPLIT_RULES
                     if cuts is not None:
+                        if cm.split_ready is not None:
+                            # the offset-range plans were built on the prep stream while this stream ran the encoder
+                            torch.cuda.current_stream().wait_event(cm.split_ready)
+                            cm.split_ready = None
                         return cm.plan_k3_split(ts, cuts), ts
                 return cm.plan_k3(ts, self.dilation), ts
             if ks == 2 and st == 2:

@@ -8,8 +8,9 @@
 Reference call sites: app/inference_engine.py:405-417,446-454,540-551; test_segmentation.py:62-72;
 train_segmentation.py:78; data/alivev2.py:363.  Everything numeric is a libsvhip.so call (include/sv_hip.h).
 """
+import threading
 import weakref
-from ctypes import c_float, c_int, c_int64, c_size_t
+from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 from enum import Enum
 
 import torch
@@ -169,6 +170,9 @@ class CoordinateManager:
         self._batch_bounds = {}
         self.num_batches = None
         self.phase_hook = None  # set per frame by app/pipeline.py FramePipeline.run (see model/backbone/minkunet.py)
+        self.split_rules = None  # [(min_rows, cuts)] of this frame's wide 3x3x3 layers; None = nn.SPLIT_RULES
+        self.split_ready = None  # event: the offset-range plans, built on another stream while the encoder runs, are there
+        self._arenas = []  # the frame composites' arenas (every map / plan array built by them is a view of one)
 
     def _own(self, plan, nbr, ld, mask, in_stride, out_stride):
         plan.cm, plan.raw, plan.in_stride, plan.out_stride = weakref.ref(self), (nbr, ld, mask), in_stride, out_stride
@@ -295,6 +299,89 @@ class CoordinateManager:
             self.plans[key] = self._own(self._build_plan(nbr, max(V, 1), mask, 8, V), nbr, max(V, 1), mask, stride, fs)
         return self.plans[key]
 
+    # ---- frame composites (sv_frame_plans): everything a U-Net asks for in one or two host calls ------------
+    def split_cuts_for(self, rows):
+        """split points of the wide 3x3x3 layers on a map of `rows` voxels (None = one pass)"""
+        if self.split_rules is None:
+            from . import nn as svnn
+
+            return svnn.split_points_for(rows)
+        for min_rows, cuts in self.split_rules:
+            if rows >= min_rows:
+                return cuts
+        return None
+
+    def build_plans(self, levels, k3=True, down=True, up=True, split=True):
+        """Hash tables, kernel maps and conv plans of pyramid levels 0..levels through ONE sv_frame_plans call (what
+        plan_k3 / plan_down / plan_up / plan_k3_split build piece by piece; the same arrays).  The maps of every level
+        must exist (TensorField.sparse(pyramid_levels=...) or stride_map)."""
+        lib = _lib.load()
+        L = levels
+        ms = [self.stride_map(1 << l) for l in range(L + 1)]
+        V = (c_int64 * (L + 1))(*[m.V for m in ms])
+        flags = ((_lib.SV_FRAME_K3 if k3 else 0) | (_lib.SV_FRAME_DOWN if down else 0) | (_lib.SV_FRAME_UP if up else 0))
+        cuts_of = {}
+        cuts_arr = (c_int32 * ((L + 1) * _lib.SV_FRAME_MAX_CUTS))()
+        if split:
+            for l in range(L + 1):
+                cuts = self.split_cuts_for(ms[l].V)
+                if cuts is None or ("k3split", 1 << l, cuts) in self.plans:
+                    continue
+                tup = (cuts,) if isinstance(cuts, int) else tuple(cuts)
+                if len(tup) > _lib.SV_FRAME_MAX_CUTS:
+                    continue  # more passes than the composite takes: plan_k3_split builds them piecewise on demand
+                cuts_of[l] = cuts
+                for i, c in enumerate(tup):
+                    cuts_arr[l * _lib.SV_FRAME_MAX_CUTS + i] = c
+            if cuts_of:
+                flags |= _lib.SV_FRAME_SPLIT
+        if flags == 0:
+            return
+        pv = lambda ts: (c_void_p * (L + 1))(*[(t.data_ptr() if t is not None else None) for t in ts])  # noqa: E731
+        keys = pv([m.keys for m in ms])
+        coords = pv([m.coords for m in ms])
+        parent = pv([self.parents[1 << l][0] if (1 << l) in self.parents else None for l in range(L + 1)])
+        k3n = k3m = None
+        if (flags & _lib.SV_FRAME_SPLIT) and not k3:
+            whole = [self.plan_k3(1 << l) if l in cuts_of else None for l in range(L + 1)]
+            k3n = pv([w.raw[0] if w is not None else None for w in whole])
+            k3m = pv([w.raw[2] if w is not None else None for w in whole])
+        nbytes = lib.sv_frame_plans_arena_bytes(V, c_int(L), c_int(flags), cuts_arr)
+        arena = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        sbytes = lib.sv_frame_plans_scratch_bytes(V, c_int(L))
+        scratch = torch.empty(sbytes, dtype=torch.uint8, device=self.device)
+        max_rec = 8 * (L + 1) + 8
+        layout = (c_int64 * (_lib.SV_FRAME_RECORD * (1 + max_rec)))()
+        call("sv_frame_plans", keys, coords, parent, V, c_int(L), c_int(flags), cuts_arr, k3n, k3m, ptr(arena), c_size_t(nbytes),
+             ptr(scratch), c_size_t(sbytes), layout, c_int(max_rec), stream_ptr())
+        self._arenas.append(arena)
+        i32 = lambda off, n: arena[off: off + 4 * n].view(torch.int32)  # noqa: E731
+        pending_split = {}
+        for r in range(layout[1]):
+            rec = layout[_lib.SV_FRAME_RECORD * (1 + r): _lib.SV_FRAME_RECORD * (2 + r)]
+            kind, l, k0, k1, o_nbr, o_mask, o_perm, o_nbrs, o_sub, o_tile, V_out, Vpad, K, ld, o_tk, cap = rec
+            stride = 1 << l
+            if kind == _lib.SV_FRAME_REC_HASH:
+                ms[l]._hash = (arena[o_tk: o_tk + 8 * cap].view(torch.int64), i32(o_nbr, cap), cap)
+                continue
+            plan = ConvPlan(i32(o_perm, Vpad), i32(o_nbrs, K * Vpad).view(K, Vpad), i32(o_sub, (Vpad // SV_TILE_ROWS) * K).view(-1, K),
+                            i32(o_tile, Vpad // SV_TILE_ROWS), V_out, Vpad, K)
+            mask = i32(o_mask, ld)
+            if kind == _lib.SV_FRAME_REC_SPLIT:
+                whole = self.plans[("k3", stride, 1)]
+                nbr = i32(o_nbr, K * ld).view(K, ld) if o_nbr >= 0 else whole.raw[0][k0:k1]
+                pending_split.setdefault(l, []).append((k0, k1, self._own(plan, nbr, ld, mask, stride, stride)))
+                continue
+            nbr = i32(o_nbr, K * ld).view(K, ld)
+            if kind == _lib.SV_FRAME_REC_K3:
+                self.plans[("k3", stride, 1)] = self._own(plan, nbr, ld, mask, stride, stride)
+            elif kind == _lib.SV_FRAME_REC_DOWN:
+                self.plans[("down", stride)] = self._own(plan, nbr, ld, mask, stride, stride * 2)
+            elif kind == _lib.SV_FRAME_REC_UP:
+                self.plans[("up", stride * 2)] = self._own(plan, nbr, ld, mask, stride * 2, stride)
+        for l, parts in pending_split.items():
+            self.plans[("k3split", 1 << l, cuts_of[l])] = SplitPlan(parts, self.plans[("k3", 1 << l, 1)])
+
     def batch_offsets(self, stride, B):
         key = (stride, B)
         if key not in self._batch_offsets:
@@ -336,6 +423,47 @@ def _voxelize(coords, device, coords_are_int):
         raise _lib.SvHipError(
             f"{bad} points have coordinates outside the key range (|coord| < 2^17 voxels, 0 <= batch < 1024)")
     return CoordinateMap(keys[:V], vcoords[:V], V, 1), inverse[:N], order[:N], seg_start[: V + 1]
+
+
+_tls = threading.local()
+
+
+def _pinned_counters(n):
+    """per-thread pinned int32 buffer the frame composite reads its level sizes back through (the call synchronises on
+    its own kernels before it returns, so one buffer per host thread is enough)"""
+    buf = getattr(_tls, "counters", None)
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(max(n, 64), dtype=torch.int32).pin_memory()
+        _tls.counters = buf
+    return buf
+
+
+def _voxelize_frame(coords, device, coords_are_int, levels):
+    """sv_frame_maps: voxelisation and the `levels` stride-2 maps of a frame in one host call.  Returns (CoordinateManager
+    with maps 1 .. 2^levels and their parent tables, inverse, order, seg_start) - the arrays sv_voxelize + sv_stride_map
+    produce piece by piece."""
+    N = coords.shape[0]
+    lib = _lib.load()
+    abytes = lib.sv_frame_maps_arena_bytes(c_int64(N), c_int(levels))
+    sbytes = lib.sv_frame_maps_scratch_bytes(c_int64(N))
+    arena = torch.empty(abytes, dtype=torch.uint8, device=device)
+    scratch = torch.empty(sbytes, dtype=torch.uint8, device=device)
+    counters = _pinned_counters(4 * (levels + 2))
+    layout = (c_int64 * (8 + 6 * (levels + 1)))()
+    call("sv_frame_maps", ptr(coords), c_int(1 if coords_are_int else 0), c_int64(N), c_int(levels), ptr(arena), c_size_t(abytes),
+         ptr(scratch), c_size_t(sbytes), c_void_p(counters.data_ptr()), layout, stream_ptr())
+    cm = CoordinateManager(device)
+    cm._arenas.append(arena)
+    view = lambda off, nbytes, dt: arena[off: off + nbytes].view(dt)  # noqa: E731
+    Vs = [layout[8 + 6 * l] for l in range(levels + 1)]
+    for l in range(levels + 1):
+        V = Vs[l]
+        o_keys, o_coords, o_parent, o_child = layout[9 + 6 * l: 13 + 6 * l]
+        cm.maps[1 << l] = CoordinateMap(view(o_keys, 8 * V, torch.int64), view(o_coords, 16 * V, torch.int32).view(V, 4), V, 1 << l)
+        if l < levels:
+            cm.parents[1 << l] = (view(o_parent, 4 * V, torch.int32), view(o_child, 4 * (Vs[l + 1] + 1), torch.int32))
+    V0 = Vs[0]
+    return (cm, view(layout[3], 8 * N, torch.int64), view(layout[4], 4 * N, torch.int32), view(layout[5], 4 * (V0 + 1), torch.int32))
 
 
 def _voxel_reduce(feats, order, seg_start, V, mode):
@@ -383,16 +511,23 @@ class TensorField:
     def __len__(self):
         return self._F.shape[0]
 
-    def sparse(self):
-        """Voxelise: floor the coordinates, unique voxels in canonical order, per-voxel feature mean."""
+    def sparse(self, pyramid_levels=None):
+        """Voxelise: floor the coordinates, unique voxels in canonical order, per-voxel feature mean.
+        pyramid_levels = n (this build's extension): the stride-2 maps of the next n pyramid levels are built in the same
+        host call (sv_frame_maps) - what a U-Net's strided convolutions would otherwise ask for one by one, each with
+        its own size read-back."""
         if self._C is None:
             raise ValueError("TensorField has no coordinates")
         if self.quantization_mode not in (SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE,
                                           SparseTensorQuantizationMode.RANDOM_SUBSAMPLE):
             raise NotImplementedError(f"quantization_mode {self.quantization_mode}")
-        cmap, inverse, order, seg_start = _voxelize(self._C, self.device, coords_are_int=False)
-        cm = CoordinateManager(self.device)
-        cm.maps[1] = cmap
+        if pyramid_levels is not None and self._C.shape[0] > 0:
+            cm, inverse, order, seg_start = _voxelize_frame(self._C, self.device, False, pyramid_levels)
+            cmap = cm.maps[1]
+        else:
+            cmap, inverse, order, seg_start = _voxelize(self._C, self.device, coords_are_int=False)
+            cm = CoordinateManager(self.device)
+            cm.maps[1] = cmap
         self.coordinate_manager = cm
         self.inverse_mapping = inverse
         self._order, self._seg_start = order, seg_start

@@ -22,7 +22,7 @@ def test_header_symbols_are_exported_and_bound():
         assert hasattr(lib, name), f"{name} declared in include/sv_hip.h but not exported by libsvhip.so"
     # the ctypes table covers exactly the header
     assert sorted(mrcc_amd._lib.SIGNATURES) == declared
-    assert lib.sv_abi_version() == 3 == mrcc_amd._lib.ABI_VERSION
+    assert lib.sv_abi_version() == 4 == mrcc_amd._lib.ABI_VERSION
 
 
 def test_argument_validation_without_gpu():

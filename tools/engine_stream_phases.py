@@ -29,6 +29,18 @@ for i in range(8):
 torch.cuda.synchronize()
 print(f"predict_segmentation, one frame at a time: {(time.perf_counter() - t0) / 8 * 1e3:.2f} ms/frame "
       f"(EE labels kept in the last frame: {(ref == 2).sum()})")
+one = getattr(eng, "_one_frame_stream", None)
+if one is not None:
+    one.host_s = {k: 0 for k in one.host_s}
+    lat = []
+    for i in range(8, 24):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.predict_segmentation(*frames[i])
+        lat.append((time.perf_counter() - t0) * 1e3)
+    n = one.host_s["frames"]
+    ph = ", ".join(f"{k} {v / n * 1e3:.2f}" for k, v in one.host_s.items() if k != "frames")
+    print(f"   per call: median {np.median(lat):.2f} ms, min {min(lat):.2f}, max {max(lat):.2f}; host ms/frame: {ph}")
 for streams in [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4]:
     list(eng.predict_segmentation_stream(iter(frames[:8]), compute_streams=streams))
     st = eng._seg_streams[(streams, 50)]
