@@ -63,7 +63,7 @@ const char* sv_last_error(void);
  * 3: sv_plan_build takes nbr_base (plans of a batch range of a kernel map); sv_key_point_predictions,
  *    sv_conv_last_instance and sv_conv_fwd_acc (offset-range passes of one layer) added
  * 4: sv_conv_set_dispatch (per-thread dispatch thresholds: one frame alone vs frames overlapped), the frame composites
- *    sv_frame_maps / sv_frame_plans (a frame's coordinate work as two host calls), sv_topk_mean_rows (get_pred_center),
+ *    sv_frame_maps / sv_frame_plans (a frame's coordinate work as two host calls), sv_topk_indices (get_pred_center),
  *    sv_key_point_predictions_batched */
 #define SV_ABI_VERSION 4
 int sv_abi_version(void);
@@ -279,6 +279,19 @@ int sv_slice_argmax(const float* F, int64_t ld, int C, const int64_t* inverse, i
  * round trip between softmax, max and threshold. */
 int sv_key_point_predictions(const float* logits, int64_t ld, int C, int64_t N, float conf_th, void* workspace,
                              size_t workspace_bytes, float* prob, int64_t* idx, int32_t* selected, sv_stream_t stream);
+
+/* The same selection for G clouds whose rows are consecutive segments of `logits` (the crops of G frames in one sparse
+ * tensor): segment g = rows seg_start_host[g] .. seg_start_host[g + 1] (HOST array, G + 1 entries); outputs [G][C], idx
+ * relative to the segment's first row.  workspace: 8 C G bytes.  Segment by segment the result of the single call. */
+int sv_key_point_predictions_batched(const float* logits, int64_t ld, int C, const int64_t* seg_start_host, int G, float conf_th,
+                                     void* workspace, size_t workspace_bytes, float* prob, int64_t* idx, int32_t* selected,
+                                     sv_stream_t stream);
+/* idx[j] = row of the j-th largest x[i * ld], i < N, j < k <= 64 (ties: the lower row first; -1 when N < k; NaN orders
+ * above +inf as in torch.sort) - the `out[:, 1].sort(descending=True)[1][:8]` of utils/output.py:45-64 get_pred_center
+ * without sorting N votes.  workspace: sv_topk_workspace_bytes(N, k). */
+size_t sv_topk_workspace_bytes(int64_t N, int k);
+int sv_topk_indices(const float* x, int64_t ld, int64_t N, int k, void* workspace, size_t workspace_bytes, int64_t* idx,
+                    sv_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A9/A10/A12  dense solves, one wavefront per problem, float64

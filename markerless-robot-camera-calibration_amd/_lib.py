@@ -72,6 +72,9 @@ SIGNATURES = {
     "sv_slice_rows": (c_int, [_P, c_int64, c_int, _P, c_int64, _P, _P]),
     "sv_slice_argmax": (c_int, [_P, c_int64, c_int, _P, c_int64, _P, _P, _P]),
     "sv_key_point_predictions": (c_int, [_P, c_int64, c_int, c_int64, c_float, _P, c_size_t, _P, _P, _P, _P]),
+    "sv_key_point_predictions_batched": (c_int, [_P, c_int64, c_int, _P, c_int, c_float, _P, c_size_t, _P, _P, _P, _P]),
+    "sv_topk_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "sv_topk_indices": (c_int, [_P, c_int64, c_int64, c_int, _P, c_size_t, _P, _P]),
     "sv_kabsch_batched": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P]),
     "sv_quat_avg_batched": (c_int, [_P, _P, _P, c_int, c_int, _P, _P]),
     "sv_add_metric_batched": (c_int, [_P, _P, c_int, _P, _P, c_int, _P, _P]),

@@ -28,8 +28,9 @@ from ..utils import calibration as calib_util
 from ..utils import config, metrics, preprocess
 from ..utils import output as out_utils
 from ..utils.data import get_farthest_point_sample_idx
-from ..utils.transformation import (get_base2cam_pose, get_q_from_matrix, get_quaternion_rotation_matrix,
-                                    get_rigid_transform_3D, transform_pose2pose)
+from ..utils.transformation import (get_base2cam_matrix, get_base2cam_pose, get_q_from_matrix,
+                                    get_quaternion_rotation_matrix, get_rigid_transform_3D,
+                                    get_rigid_transform_3D_batched, transform_pose2pose)
 from .dto import CalibrationResultDTO, PointCloudDTO, ResultDTO, TestResultDTO
 
 # app/inference_engine.py:128-137
@@ -169,15 +170,82 @@ class InferenceEngine:
                                            compute_streams=compute_streams)
         return streams[key].run(frames)
 
-    def predict_rotation(self, ee_raw_points, ee_rgb):
+    # ---- pose stages on end-effector crops (reference :437-559), one or several crops per network run ---------------
+    def _crop_runner(self):
+        from .pipeline import CropBatchRunner
+
+        r = self.__dict__.get("_crops")
+        if r is None:
+            r = self._crops = CropBatchRunner(self.device, levels=4)
+        return r
+
+    def _pose_nets_share_voxels(self):
+        """the rotation and the key-point network read the same voxelised crop (same centring, scale and colour features:
+        the default configuration, config/default.yaml:129-160) - one sparse tensor, one set of maps and plans for both"""
         cfg = self._config
-        pts = np.asarray(ee_raw_points)
-        if cfg.INFERENCE.ROTATION.center_at_origin:
-            pts, _ = preprocess.center_at_origin(pts)
-        with torch.no_grad():
-            x = self._field(pts, ee_rgb, cfg.INFERENCE.ROTATION.scale).sparse()
-            out = self._rotation_model(x)
-        return out[0][3:].cpu().numpy()  # quaternion (+ confidences when STRUCTURE.compute_confidence), :446-454
+        r, k = cfg.INFERENCE.ROTATION, cfg.INFERENCE.KEY_POINTS
+        return (k.backbone != "pointnet2" and r.scale == k.scale and bool(r.center_at_origin) == bool(k.center_at_origin)
+                and not k.use_coordinates_as_features)
+
+    def _pose_nets_enqueue(self, crops_pts, crops_rgb, conf_th, one_frame):
+        """rotation network AND key-point network (+ its batched selection) on one voxelisation of G crops; returns
+        ((rot host view, event, keep), (kp host views, event, keep))"""
+        cfg = self._config
+        pts = []
+        for p in crops_pts:
+            p = np.asarray(p)
+            if cfg.INFERENCE.ROTATION.center_at_origin:
+                p, _ = preprocess.center_at_origin(p)
+            pts.append(p)
+        G = len(pts)
+        runner = self._crop_runner()
+
+        def nets(x, field, seg_start):
+            return self._rotation_model(x), self._kp_select(x, field, seg_start, G, conf_th)
+
+        rot, kp = runner.run(pts, crops_rgb, cfg.INFERENCE.ROTATION.scale, nets, one_frame=one_frame)
+        (host,), ev, keep = runner.download([rot])
+        return (host, ev, keep), runner.download(list(kp))
+
+    def _kp_select(self, x, field, seg_start, G, conf_th):
+        """key-point network on the voxelised batch x, slice to the points, per-crop selection of utils/output.py:81-87 for
+        all crops (sv_key_point_predictions_batched) -> (prob, idx, selected) [G, C] on the device"""
+        from ctypes import c_float, c_int, c_int64, c_size_t
+
+        from .._lib import call, ptr, stream_ptr
+
+        logits = self._key_points_model(x).slice(field).features
+        C = logits.shape[1]
+        dev = logits.device
+        buf = torch.empty(G * C, dtype=torch.int64, device=dev)
+        idx = torch.empty((G, C), dtype=torch.int64, device=dev)
+        prob = torch.empty((G, C), dtype=torch.float32, device=dev)
+        sel = torch.empty((G, C), dtype=torch.int32, device=dev)
+        segs = (c_int64 * (G + 1))(*seg_start)
+        call("sv_key_point_predictions_batched", ptr(logits), c_int64(logits.stride(0)), c_int(C), segs, c_int(G),
+             c_float(conf_th), ptr(buf), c_size_t(8 * G * C), ptr(prob), ptr(idx), ptr(sel), stream_ptr())
+        return prob, idx, sel
+
+    def _rotation_enqueue(self, crops_pts, crops_rgb, one_frame):
+        """the rotation network on G crops as one sparse tensor (batch column = crop): enqueued on the crop stream, its
+        [G, 7 or 10] output on its way to pinned memory; returns (host view, event, keep-alive)"""
+        cfg = self._config
+        pts = []
+        for p in crops_pts:
+            p = np.asarray(p)
+            if cfg.INFERENCE.ROTATION.center_at_origin:
+                p, _ = preprocess.center_at_origin(p)
+            pts.append(p)
+        runner = self._crop_runner()
+        out = runner.run(pts, crops_rgb, cfg.INFERENCE.ROTATION.scale, lambda x, field, seg: self._rotation_model(x),
+                         encoder_only=bool(cfg.INFERENCE.ROTATION.encode_only), one_frame=one_frame)
+        (host,), ev, keep = runner.download([out])
+        return host, ev, keep
+
+    def predict_rotation(self, ee_raw_points, ee_rgb):
+        host, ev, _ = self._rotation_enqueue([ee_raw_points], [ee_rgb], one_frame=True)
+        ev.synchronize()
+        return np.array(host[0][3:].numpy())  # quaternion (+ confidences when STRUCTURE.compute_confidence), :446-454
 
     def predict_translation(self, ee_raw_points, ee_rgb, q=None):
         cfg = self._config
@@ -197,36 +265,57 @@ class InferenceEngine:
         magic = np.array([-0.015, 0.0, min_z]) + offset
         return rot_mat @ magic, offset
 
+    def _key_points_enqueue(self, crops_pts, crops_rgb, conf_th, one_frame):
+        """the key-point network (sparse U-Net backbone) on G crops as one sparse tensor, then the per-crop selection of
+        utils/output.py:81-87 for all of them (sv_key_point_predictions_batched); returns (host views [prob, idx, selected],
+        event, keep-alive)"""
+        cfg = self._config
+        kp = cfg.INFERENCE.KEY_POINTS
+        pts, feats = [], []
+        for p, f in zip(crops_pts, crops_rgb):
+            p = np.array(np.asarray(p), copy=True)
+            if kp.center_at_origin:
+                p, _ = preprocess.center_at_origin(p)
+            if kp.use_coordinates_as_features:
+                f = preprocess.normalize_points(p)
+            pts.append(p)
+            feats.append(f)
+        G = len(pts)
+
+        runner = self._crop_runner()
+        outs = runner.run(pts, feats, kp.scale, lambda x, field, seg: self._kp_select(x, field, seg, G, conf_th),
+                          one_frame=one_frame)
+        return runner.download(list(outs))
+
     def predict_key_points(self, raw_points, rgb, conf_th=None):
         cfg = self._config
         kp = cfg.INFERENCE.KEY_POINTS
         raw_points = np.asarray(raw_points)
+        th = conf_th or kp.conf_threshold
+        if kp.backbone != "pointnet2":
+            (prob, idx, sel), ev, _ = self._key_points_enqueue([raw_points], [rgb], th, one_frame=True)
+            ev.synchronize()
+            classes = np.where(sel[0].numpy() != 0)[0]
+            return raw_points[idx[0].numpy()[classes]], classes, torch.from_numpy(np.array(prob[0].numpy()[classes]))
         points = np.array(raw_points, copy=True)
         if kp.center_at_origin:
             points, _ = preprocess.center_at_origin(points)
         if kp.use_coordinates_as_features:
             rgb = preprocess.normalize_points(points)
         rgb_t = rgb if torch.is_tensor(rgb) else torch.from_numpy(np.asarray(rgb)).to(torch.float32)
-        th = conf_th or kp.conf_threshold
         with torch.no_grad():
-            if kp.backbone == "pointnet2":
-                n_dense = cfg.INFERENCE.num_of_dense_input_points
-                if len(points) < n_dense:
-                    return [], [], []
-                if kp.pointcloud_sampling_method == "uniform":
-                    sample_idx = np.random.choice(len(points), n_dense, replace=False)
-                else:
-                    sample_idx = get_farthest_point_sample_idx(points, n_dense)
-                pts_t = torch.from_numpy(points).to(torch.float32)
-                inp = torch.cat((pts_t[sample_idx], rgb_t.cpu()[sample_idx]), dim=-1).view(1, n_dense, -1)
-                out = self._key_points_model(inp.transpose(2, 1).to(self.device))[0].view(n_dense, -1)
-                kp_idx, kp_classes, probs = out_utils.get_key_point_predictions(out, conf_th=th)
-                kp_idx = sample_idx[kp_idx]
+            n_dense = cfg.INFERENCE.num_of_dense_input_points
+            if len(points) < n_dense:
+                return [], [], []
+            if kp.pointcloud_sampling_method == "uniform":
+                sample_idx = np.random.choice(len(points), n_dense, replace=False)
             else:
-                field = self._field(points, rgb_t, kp.scale)
-                out = self._key_points_model(field.sparse())
-                logits = out.slice(field).features
-                kp_idx, kp_classes, probs = out_utils.get_key_point_predictions(logits, conf_th=th)
+                sample_idx = get_farthest_point_sample_idx(points, n_dense)
+            pts_t = torch.from_numpy(points).to(torch.float32)
+            inp = torch.cat((pts_t[sample_idx], rgb_t.cpu()[sample_idx]), dim=-1).view(1, n_dense, -1)
+            out = self._key_points_model(inp.transpose(2, 1).to(self.device))[0].view(n_dense, -1)
+            kp_idx, kp_classes, probs = out_utils.get_key_point_predictions(out, conf_th=th)
+            kp_idx = sample_idx[kp_idx]
         return raw_points[kp_idx], kp_classes, probs
 
     def check_sanity(self, data: PointCloudDTO, result: ResultDTO, kp_error_margin=None):
@@ -251,13 +340,20 @@ class InferenceEngine:
         if not self.pred_enabled:
             return ResultDTO(segmentation=np.zeros(len(data.points), dtype=np.int64))
         rgb = preprocess.normalize_colors(data.rgb)
-        return self._predict_after_segmentation(data, rgb, self.predict_segmentation(data.points, rgb))
+        seg = self.predict_segmentation(data.points, rgb)
+        return self._pose_collect(self._pose_enqueue([(data, rgb, seg)], one_frame=True))[0]
 
-    def predict_stream(self, frames, compute_streams=3):
-        """predict() over a sequence of PointCloudDTOs with the segmentation stage pipelined across frames
-        (predict_segmentation_stream); the pose stages of a frame (end-effector crop: a few thousand points) run when its
-        labels arrive, while the following frames' segmentation networks are already on the GPU.  Yields the same
-        ResultDTOs, in order, as calling predict() frame by frame."""
+    def predict_stream(self, frames, compute_streams=3, group=4, pose_thread=True):
+        """predict() over a sequence of PointCloudDTOs, everything pipelined: the segmentation stage across frames
+        (predict_segmentation_stream), and the pose stages (reference :304-319: rotation network, translation, key-point
+        network, key-point selection, Kabsch, base poses) for GROUPS of `group` consecutive frames - their end-effector crops
+        form one sparse tensor per network (batch column = frame), the selection and the rigid-transform solves run once per
+        group, and a group's results are collected only after the next group's work has been enqueued, so the host never
+        waits for a pose kernel while segmentation networks could be launched.  pose_thread: the groups' pose work (its
+        launches, and above all its blocking size read-backs and result waits, which sit behind the crop stream's kernels)
+        runs on a second host thread, so that the thread feeding the segmentation pipeline never waits for it.  Yields the
+        same ResultDTOs, in order, as calling predict() frame by frame (results arrive up to 2 * group - 1 frames after
+        their input)."""
         if not self.pred_enabled:
             for data in frames:
                 yield ResultDTO(segmentation=np.zeros(len(data.points), dtype=np.int64))
@@ -270,34 +366,191 @@ class InferenceEngine:
                 window.append((data, rgb))
                 yield data.points, rgb
 
-        for seg in self.predict_segmentation_stream(inputs(), compute_streams=compute_streams):
-            data, rgb = window.popleft()
-            yield self._predict_after_segmentation(data, rgb, seg)
+        cur, pending = [], collections.deque()
+        seg_stream = self.predict_segmentation_stream(inputs(), compute_streams=compute_streams)
+        if not pose_thread:
+            for seg in seg_stream:
+                data, rgb = window.popleft()
+                cur.append((data, rgb, seg))
+                if len(cur) >= group:
+                    pending.append(self._pose_enqueue(cur, one_frame=False))
+                    cur = []
+                    while len(pending) > 1:
+                        yield from self._pose_collect(pending.popleft())
+            if cur:
+                pending.append(self._pose_enqueue(cur, one_frame=False))
+            while pending:
+                yield from self._pose_collect(pending.popleft())
+            return
+        import queue
+        import threading
+
+        jobs, done = queue.Queue(), queue.Queue()
+
+        def worker():
+            try:
+                if self.device.index is not None:
+                    torch.cuda.set_device(self.device)
+                waiting = None  # one group enqueued ahead of the one being collected
+                while True:
+                    items = jobs.get()
+                    nxt = self._pose_enqueue(items, one_frame=False) if items is not None else None
+                    if waiting is not None:
+                        done.put(self._pose_collect(waiting))
+                    waiting = nxt
+                    if items is None:
+                        return
+            except BaseException as e:  # whatever happens on this thread is handed to the consumer, which re-raises it
+                done.put(e)
+
+        th = threading.Thread(target=worker, name="mrcc-pose", daemon=True)
+        th.start()
+        outstanding = 0
+
+        def ready(block):
+            nonlocal outstanding
+            while outstanding:
+                try:
+                    r = done.get(block=block, timeout=1.0 if block else None)
+                except queue.Empty:
+                    if not block:
+                        return
+                    if not th.is_alive() and done.empty():  # never wait for a thread that is gone
+                        raise RuntimeError("the pose thread ended without delivering its results")
+                    continue
+                if isinstance(r, BaseException):
+                    raise r
+                outstanding -= 1
+                yield from r
+
+        try:
+            for seg in seg_stream:
+                data, rgb = window.popleft()
+                cur.append((data, rgb, seg))
+                if len(cur) >= group:
+                    jobs.put(cur)
+                    outstanding += 1
+                    cur = []
+                yield from ready(block=False)
+            if cur:
+                jobs.put(cur)
+                outstanding += 1
+            jobs.put(None)
+            yield from ready(block=True)
+        finally:
+            if th.is_alive():
+                jobs.put(None)
+            th.join(timeout=60)
 
     def _predict_after_segmentation(self, data, rgb, seg):
+        return self._pose_collect(self._pose_enqueue([(data, rgb, seg)], one_frame=True))[0]
+
+    def _pose_enqueue(self, items, one_frame):
+        """items: [(PointCloudDTO, normalised colours, labels)].  Crops the end effector of every frame (host: the labels
+        are host arrays, as in the reference :297-303) and enqueues the rotation and key-point networks for all crops that
+        pass the point-count threshold; nothing here waits for the GPU."""
         cfg = self._config
-        result = ResultDTO(segmentation=seg)
-        ee_idx = np.where(seg == 2)[0]
-        if len(ee_idx) < cfg.INFERENCE.ee_point_counts_threshold:
-            return result
-        ee_pts = data.points[ee_idx]
-        ee_rgb = torch.from_numpy(rgb[ee_idx]).to(dtype=torch.float32)
-        q = self.predict_rotation(ee_pts, ee_rgb)
-        pos, _ = self.predict_translation(ee_pts, ee_rgb, q=q)
-        result.ee_pose = np.concatenate((pos, q))
-        kp_coords, kp_classes, _ = self.predict_key_points(ee_pts, ee_rgb)
-        result.key_points = list(zip(kp_classes, kp_coords))
-        result.key_points_pose = self.predict_pose_from_kp(kp_coords, kp_classes)
-        result.is_confident = self.check_sanity(data, result)
-        if self.match_icp is not None:  # app/inference_engine.py:358-362
-            result.ee_pose = self.match_icp(ee_pts, result.ee_pose)
-            result.key_points_pose = self.match_icp(ee_pts, result.key_points_pose)
-        if data.ee2base_pose is not None:
-            if result.ee_pose is not None:  # the ICP step may have rejected the pose (:364-369)
-                result.base_pose = get_base2cam_pose(result.ee_pose, data.ee2base_pose)
+        crops = []
+        for data, rgb, seg in items:
+            ee_idx = np.where(seg == 2)[0]
+            if len(ee_idx) < cfg.INFERENCE.ee_point_counts_threshold:
+                crops.append(None)
+            else:
+                crops.append((data.points[ee_idx], rgb[ee_idx]))
+        live = [c for c in crops if c is not None]
+        handle = {"items": items, "crops": crops, "rot": None, "kp": None}
+        if live:
+            pts, cols = [c[0] for c in live], [c[1] for c in live]
+            if self._pose_nets_share_voxels():
+                handle["rot"], handle["kp"] = self._pose_nets_enqueue(pts, cols, cfg.INFERENCE.KEY_POINTS.conf_threshold,
+                                                                      one_frame)
+            else:
+                handle["rot"] = self._rotation_enqueue(pts, cols, one_frame)
+                if cfg.INFERENCE.KEY_POINTS.backbone != "pointnet2":
+                    handle["kp"] = self._key_points_enqueue(pts, cols, cfg.INFERENCE.KEY_POINTS.conf_threshold, one_frame)
+        return handle
+
+    def _pose_collect(self, handle):
+        """wait for a group's networks (one event each), then the host side of the pose stages per frame and the group's
+        rigid-transform problems - key-point Kabsch and the quaternions of the base poses - as two batched solves"""
+        cfg = self._config
+        results = []
+        rot = kp = None
+        if handle["rot"] is not None:
+            host, ev, _ = handle["rot"]
+            ev.synchronize()
+            rot = np.array(host.numpy())
+        if handle["kp"] is not None:
+            (prob, idx, sel), ev, _ = handle["kp"]
+            ev.synchronize()
+            kp = (np.array(prob.numpy()), np.array(idx.numpy()), np.array(sel.numpy()))
+        j = 0
+        work = []  # (result, data, ee_pts) of the frames that have a crop
+        for (data, rgb, seg), crop in zip(handle["items"], handle["crops"]):
+            result = ResultDTO(segmentation=seg)
+            results.append(result)
+            if crop is None:
+                continue
+            ee_pts, ee_rgb = crop
+            q = rot[j][3:]
+            pos, _ = self.predict_translation(ee_pts, None, q=q)
+            result.ee_pose = np.concatenate((pos, q))
+            if kp is not None:
+                classes = np.where(kp[2][j] != 0)[0]
+                kp_coords = ee_pts[kp[1][j][classes]]
+            else:
+                kp_coords, classes, _ = self.predict_key_points(ee_pts, torch.from_numpy(ee_rgb).to(torch.float32))
+            result.key_points = list(zip(classes, kp_coords))
+            work.append((result, data, ee_pts, np.asarray(classes), np.asarray(kp_coords)))
+            j += 1
+        if not work:
+            return results
+        # ---- solve 1: Kabsch of every frame with >= 4 key points (:384-393)
+        probs = [(self.reference_key_points[c], k) for _, _, _, c, k in work if len(c) >= 4]
+        sol = iter(self._solve_rigid(probs))
+        for result, data, ee_pts, classes, kp_coords in work:
+            if len(classes) >= 4:
+                _, t, q = next(sol)
+                result.key_points_pose = np.concatenate((t, q))
+            result.is_confident = self.check_sanity(data, result)
+            if self.match_icp is not None:  # app/inference_engine.py:358-362
+                result.ee_pose = self.match_icp(ee_pts, result.ee_pose)
+                result.key_points_pose = self.match_icp(ee_pts, result.key_points_pose)
+        # ---- solve 2: the base poses' quaternions (get_base2cam_pose -> get_q_from_matrix), all frames at once
+        mats = []
+        for result, data, *_ in work:
+            if data.ee2base_pose is None:
+                continue
+            for pose in (result.ee_pose, result.key_points_pose):  # the ICP step may have rejected a pose (:364-369)
+                if pose is not None:
+                    mats.append(get_base2cam_matrix(pose, data.ee2base_pose))
+        eye = np.concatenate([np.eye(3), np.zeros((1, 3))])  # get_q_from_matrix: identity points -> rows of R
+        sol = iter(self._solve_rigid([(eye, eye @ m[:3, :3].T) for m in mats]))
+        mi = iter(mats)
+        for result, data, *_ in work:
+            if data.ee2base_pose is None:
+                continue
+            if result.ee_pose is not None:
+                result.base_pose = np.concatenate((next(mi)[:3, 3], next(sol)[2]))
             if result.key_points_pose is not None:
-                result.key_points_base_pose = get_base2cam_pose(result.key_points_pose, data.ee2base_pose)
-        return result
+                result.key_points_base_pose = np.concatenate((next(mi)[:3, 3], next(sol)[2]))
+        return results
+
+    def _solve_rigid(self, problems):
+        """[(reference [K, 3], target [K, 3])] -> [(R, t, q)]: ONE sv_kabsch_batched launch (K <= 6 padded to 6 rows; a
+        problem's result does not depend on what else is in the batch)"""
+        if not problems:
+            return []
+        B = len(problems)
+        ref = np.zeros((B, 6, 3))
+        tgt = np.zeros((B, 6, 3))
+        K = np.zeros(B, dtype=np.int32)
+        for b, (a, t) in enumerate(problems):
+            K[b] = len(a)
+            ref[b, : len(a)] = a
+            tgt[b, : len(a)] = t
+        R, t, q = get_rigid_transform_3D_batched(ref, tgt, K=K, device=self.device)
+        return [(R[b], t[b], q[b]) for b in range(B)]
 
     # ---- calibration (reference :152-244) ---------------------------------------------------------------------
     def calibrate(self, data) -> CalibrationResultDTO:

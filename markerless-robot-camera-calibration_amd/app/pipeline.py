@@ -281,3 +281,104 @@ class HostFrameStream:
             while pending:
                 yield self._finalize(pending.popleft())
             self.pipe.drain()
+
+
+class PinnedRing:
+    """A few pinned host buffers handed out in turn; a slot is reused once the event recorded for its last transfer has
+    completed (pinning memory costs hundreds of microseconds: the buffers are kept and grown, never freed per frame)."""
+
+    def __init__(self, slots=6):
+        self.bufs = [None] * slots
+        self.events = [None] * slots
+        self.i = 0
+
+    def take(self, nbytes):
+        i = self.i
+        self.i = (i + 1) % len(self.bufs)
+        if self.events[i] is not None:
+            self.events[i].synchronize()
+            self.events[i] = None
+        buf = self.bufs[i]
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes * 1.25), 1 << 16), dtype=torch.uint8).pin_memory()
+            self.bufs[i] = buf
+        return i, buf[:nbytes]
+
+    def busy_until(self, i, event):
+        self.events[i] = event
+
+
+class CropBatchRunner:
+    """One sparse network over the end-effector crops of several frames as ONE sparse tensor - batch column = crop, the
+    training-format batch of data/alivev2.py:358-383, whose frames never interact (every crop's rows have the bits of
+    running it alone).  The reference runs its pose networks once per frame (app/inference_engine.py:304-319), each a
+    U-Net of ~50-100 launches on a few thousand voxels: launch-bound.  Batched over the frames in flight, the launches, the
+    H2D copy, the coordinate work (sv_frame_maps / sv_frame_plans) and the result download are paid once per group, on
+    this runner's own stream, beside the segmentation networks of the following frames."""
+
+    def __init__(self, device, levels=4):
+        self.device = torch.device(device)
+        self.levels = levels
+        # high priority, as the prep stream: the crops' few hundred short workgroups must not queue behind the thousands of
+        # convolution workgroups of the segmentation frames in flight (the host waits for this stream's size read-backs)
+        self.stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("MRCC_PREP_PRIORITY", "-1")))
+        self.up = PinnedRing()
+        self.down = PinnedRing(slots=12)
+
+    def run(self, pts_list, feat_list, scale, fn, encoder_only=False, one_frame=False):
+        """pts_list[i] [n_i, 3] (already preprocessed; float64 sources are rounded to float32 first, then multiplied by
+        `scale` in float32 - the product the reference forms on the host, app/inference_engine.py:446-450), feat_list[i]
+        [n_i, C].  fn(x, field, seg_start) runs on this runner's stream with x = the voxelised batch; seg_start[i] = first
+        point of crop i.  Returns fn's result (valid on self.stream).  Several networks that take the SAME voxelisation
+        (same preprocessing, scale and features) are run by one fn on one x: the maps and plans are built once."""
+        import contextlib
+
+        import numpy as np
+
+        from .. import _lib
+
+        G = len(pts_list)
+        sizes = [len(p) for p in pts_list]
+        n = int(sum(sizes))
+        C = int(np.asarray(feat_list[0]).shape[1]) if not torch.is_tensor(feat_list[0]) else int(feat_list[0].shape[1])
+        slot, buf = self.up.take(n * (4 + C) * 4)
+        host = buf.view(torch.float32).numpy()
+        hc, hf = host[: 4 * n].reshape(n, 4), host[4 * n:].reshape(n, C)
+        seg_start = [0]
+        for b in range(G):
+            o, m = seg_start[-1], sizes[b]
+            hc[o:o + m, 0] = b
+            np.multiply(np.asarray(pts_list[b], dtype=np.float32), np.float32(scale), out=hc[o:o + m, 1:])
+            f = feat_list[b]
+            hf[o:o + m] = f.detach().cpu().numpy() if torch.is_tensor(f) else np.asarray(f, dtype=np.float32)
+            seg_start.append(o + m)
+        with torch.cuda.stream(self.stream), torch.no_grad():
+            dev = buf.to(self.device, non_blocking=True).view(torch.float32)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            self.up.busy_until(slot, ev)
+            field = ME.TensorField(features=dev[4 * n:].view(n, C), coordinates=dev[: 4 * n].view(n, 4),
+                                   quantization_mode=ME.SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE,
+                                   minkowski_algorithm=ME.MinkowskiAlgorithm.SPEED_OPTIMIZED, device=self.device)
+            x = field.sparse(pyramid_levels=self.levels)
+            cm = x.coordinate_manager
+            cm.num_batches = G  # known here: no read-back of the largest batch index
+            cm.build_plans(self.levels, up=not encoder_only, split=not encoder_only)
+            with (_lib.conv_dispatch(1.0) if one_frame else contextlib.nullcontext()):
+                return fn(x, field, seg_start)
+
+    def download(self, tensors):
+        """device tensors -> (list of pinned host views, event): one asynchronous D2H each on the runner's stream"""
+        outs = []
+        with torch.cuda.stream(self.stream):
+            for t in tensors:
+                t = t.contiguous()
+                slot, buf = self.down.take(t.numel() * t.element_size())
+                h = buf.view(t.dtype).view(t.shape)
+                h.copy_(t, non_blocking=True)
+                outs.append((slot, h, t))  # the device tensor stays referenced until the copy has been waited for
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        for slot, _, _ in outs:
+            self.down.busy_until(slot, ev)
+        return [h for _, h, _ in outs], ev, [t for _, _, t in outs]

@@ -255,11 +255,90 @@ __global__ void kp_finalize_kernel(const unsigned long long* __restrict__ best, 
   selected[c] = pr > conf_th ? 1 : 0;
 }
 
+// ---- top-k of one column (utils/output.py:45-64 get_pred_center: `out[:, 1].sort(descending=True)[1][:8]` - a full sort
+//      of every point's vote to take eight).  Packed keys (order-preserving value bits << 32 | ~index): the largest key is
+//      the largest value at the lowest index, keys are distinct, so the j-th selection is "the largest key below the
+//      (j-1)-th" - no masking, no sort.  Stage 1: every block of 256 threads selects the k largest of its chunk; stage 2: one
+//      block selects the k largest of the blocks' candidates.  NaN orders above +inf (torch.sort places NaN first).
+__device__ __forceinline__ unsigned long long topk_key(float v, unsigned idx) {
+  unsigned u = __float_as_uint(v);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - idx);
+}
+
+constexpr int TOPK_CHUNK = 8192;  // values per stage-1 block
+template <bool KEYS_IN>
+__global__ __launch_bounds__(256) void topk_select_kernel(const float* __restrict__ x, int64_t ld,
+                                                           const unsigned long long* __restrict__ keys_in, int64_t n, int k,
+                                                           unsigned long long* __restrict__ keys_out) {
+  __shared__ unsigned long long wave_best[4];
+  __shared__ unsigned long long chosen;
+  const int64_t base = (int64_t)blockIdx.x * TOPK_CHUNK;
+  const int64_t end = KEYS_IN ? n : (base + TOPK_CHUNK < n ? base + TOPK_CHUNK : n);
+  unsigned long long prev = ~0ull;
+  for (int j = 0; j < k; ++j) {
+    unsigned long long best = 0ull;  // key 0 = nothing left (a real key has index bits != all-ones or value bits != 0)
+    for (int64_t i = (KEYS_IN ? 0 : base) + threadIdx.x; i < end; i += 256) {
+      const unsigned long long key = KEYS_IN ? keys_in[i] : topk_key(x[i * ld], (unsigned)i);
+      if (key < prev && key > best) best = key;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const unsigned long long o = __shfl_xor(best, off, 64);
+      best = o > best ? o : best;
+    }
+    if ((threadIdx.x & 63) == 0) wave_best[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long b = wave_best[0];
+      for (int w = 1; w < 4; ++w) b = wave_best[w] > b ? wave_best[w] : b;
+      chosen = b;
+      keys_out[(int64_t)blockIdx.x * k + j] = b;
+    }
+    __syncthreads();
+    prev = chosen ? chosen : 0ull;
+    if (prev == 0ull) {  // fewer than k values: the remaining slots stay 0 (idx -1)
+      if (threadIdx.x == 0)
+        for (int jj = j + 1; jj < k; ++jj) keys_out[(int64_t)blockIdx.x * k + jj] = 0ull;
+      break;
+    }
+  }
+}
+
+__global__ void topk_finalize_kernel(const unsigned long long* __restrict__ keys, int k, int64_t* __restrict__ idx) {
+  const int j = threadIdx.x;
+  if (j < k) idx[j] = keys[j] ? (int64_t)(0xffffffffu - (unsigned)(keys[j] & 0xffffffffull)) : -1;
+}
+
 }  // namespace sv
 
 using namespace sv;
 
 extern "C" {
+
+size_t sv_topk_workspace_bytes(int64_t N, int k) {
+  const int64_t blocks = N <= 0 ? 1 : (N + TOPK_CHUNK - 1) / TOPK_CHUNK;
+  return (size_t)(blocks + 1) * (size_t)k * sizeof(unsigned long long) + 256;
+}
+
+int sv_topk_indices(const float* x, int64_t ld, int64_t N, int k, void* workspace, size_t workspace_bytes, int64_t* idx,
+                    sv_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SV_CHECK_ARG(k >= 1 && k <= 64 && ld >= 1 && N >= 0 && N < 0xffffffffll, "bad shape (1 <= k <= 64)");
+  SV_CHECK_ARG(idx && workspace && (x || N == 0), "null pointer");
+  if (workspace_bytes < sv_topk_workspace_bytes(N, k)) {
+    set_error("sv_topk_indices: workspace too small");
+    return SV_ERR_WORKSPACE;
+  }
+  const int64_t blocks = N <= 0 ? 1 : (N + TOPK_CHUNK - 1) / TOPK_CHUNK;
+  unsigned long long* cand = (unsigned long long*)workspace;
+  unsigned long long* fin = cand + blocks * k;
+  hipLaunchKernelGGL(topk_select_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, x, ld, nullptr, N, k, cand);
+  hipLaunchKernelGGL(topk_select_kernel<true>, dim3(1), dim3(256), 0, stream, nullptr, 0, cand, blocks * k, k, fin);
+  hipLaunchKernelGGL(topk_finalize_kernel, dim3(1), dim3(64), 0, stream, fin, k, idx);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
 
 size_t sv_col_stats_workspace_bytes(int64_t N) {
   const int64_t blocks = N <= 0 ? 1 : (N + 4095) / 4096;
@@ -382,6 +461,23 @@ int sv_key_point_predictions(const float* logits, int64_t ld, int C, int64_t N, 
   }
   hipLaunchKernelGGL(kp_finalize_kernel, dim3(1), dim3(32), 0, stream, best, C, conf_th, prob, idx, selected);
   SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+int sv_key_point_predictions_batched(const float* logits, int64_t ld, int C, const int64_t* seg_start_host, int G, float conf_th,
+                                     void* workspace, size_t workspace_bytes, float* prob, int64_t* idx, int32_t* selected,
+                                     sv_stream_t stream_) {
+  SV_CHECK_ARG(G >= 0 && seg_start_host, "bad segment table");
+  SV_CHECK_ARG(workspace_bytes >= (size_t)G * (size_t)C * sizeof(unsigned long long), "workspace too small (8 C G bytes)");
+  for (int g = 0; g < G; ++g) {
+    const int64_t s = seg_start_host[g], e = seg_start_host[g + 1];
+    SV_CHECK_ARG(e >= s && s >= 0, "segment starts must ascend");
+    const int rc = sv_key_point_predictions(logits ? logits + s * ld : nullptr, ld, C, e - s, conf_th,
+                                            (char*)workspace + (size_t)g * C * sizeof(unsigned long long),
+                                            (size_t)C * sizeof(unsigned long long), prob + (size_t)g * C, idx + (size_t)g * C,
+                                            selected + (size_t)g * C, stream_);
+    if (rc) return rc;
+  }
   return SV_OK;
 }
 

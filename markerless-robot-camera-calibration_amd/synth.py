@@ -73,11 +73,13 @@ def gen_ee_crop(seed, n=4096, kp_noise=0.001):
     return pts.astype(np.float32), rgb.astype(np.float32), pose, kps
 
 
-def gen_scene(seed, n_bg=40_000, n_arm=4_000, n_ee=4_096, room=2.4):
+def gen_scene(seed, n_bg=40_000, n_arm=4_000, n_ee=4_096, room=2.4, keyed_colors=False):
     """A labelled robot scene for the evaluation harness (reference frame format, README.md:55-62): background room
     (label 0), a 4 cm-radius arm cylinder from a base point to the end effector (label 1) and the EE crop (label 2) at a
     seeded pose.  Returns dict(points, rgb in [0,1], segmentation, pose (x,y,z,qw,qx,qy,qz), key_points [6,3],
-    ee2base_pose, position)."""
+    ee2base_pose, position).  keyed_colors: the red channel is bright (>= 0.8) exactly on the end effector and the green one
+    exactly on the arm (everything else <= 0.45), so that a network carrying `wire_color_keyed_labels` labels the scene
+    by construction - an EE crop of known size whatever the other weights are."""
     rng = np.random.default_rng(20_000 + seed)
     bg, _, _ = gen_room(n_bg, room, seed)
     ee, _, pose, kps = gen_ee_crop(seed, n=n_ee)
@@ -93,7 +95,59 @@ def gen_scene(seed, n_bg=40_000, n_arm=4_000, n_ee=4_096, room=2.4):
     points = np.concatenate([bg, arm.astype(np.float32), ee]).astype(np.float32)
     seg = np.concatenate([np.zeros(len(bg), np.int64), np.ones(n_arm, np.int64), np.full(len(ee), 2, np.int64)])
     rgb = rng.uniform(0.0, 1.0, size=(len(points), 3)).astype(np.float32)
+    if keyed_colors:
+        rgb[:, :2] *= 0.45
+        rgb[seg == 2, 0] = 0.8 + 0.2 * rng.uniform(size=int((seg == 2).sum())).astype(np.float32)
+        rgb[seg == 1, 1] = 0.8 + 0.2 * rng.uniform(size=int((seg == 1).sum())).astype(np.float32)
     perm = rng.permutation(len(points))
     ee2base = np.concatenate([rng.uniform(-0.3, 0.3, size=3), random_pose(rng)[3:]])
     return {"points": points[perm], "rgb": rgb[perm], "segmentation": seg[perm], "pose": pose, "key_points": kps,
             "ee2base_pose": ee2base, "position": f"p{seed % 3 + 1}"}
+
+
+def wire_color_keyed_labels(model, gain=10.0):
+    """Make a (randomly initialised) RobotNetSegmentation label by INPUT COLOUR, without taking work out of the network:
+    two channels are wired from the input to the logits - red -> channel 0, green -> channel 1 through conv0's centre
+    offset, the level-0 skip connection, block8's residual path, `final` and `regression.0` (every weight that would mix
+    another value into those two channels is zeroed) - and `regression.2` reads only them: class 2 (end effector) where the
+    voxel's mean red exceeds ~0.1 above mid-grey, class 1 (arm) where green does, class 0 elsewhere.  All other weights
+    keep their random values, so every layer still multiplies full-size random operands (the kernels, their work and the
+    clocks they sustain are those of a trained network), while `gen_scene(keyed_colors=True)` frames come out with their
+    ground-truth labels by construction: tests and benchmarks of the stages BEHIND the segmentation (cluster rule, EE crop,
+    pose networks, key points, Kabsch) no longer depend on what random weights happen to predict.  BatchNorm layers must be
+    at their default running statistics on the wired channels (fresh models are).  In place; returns the model."""
+    import torch
+
+    with torch.no_grad():
+        c0 = model.conv0p1s1.kernel  # [27, 3, 32]
+        c0[:, :, 0:2] = 0.0
+        c0[13, 0, 0] = 1.0
+        c0[13, 1, 1] = 1.0
+        n = model.N_LEVELS
+        last_block = getattr(model, f"block{2 * n}")
+        up_planes = getattr(model, model._up_names(2 * n - 1)[0]).out_channels  # columns of the transposed conv in the cat
+        b0 = last_block[0]
+        if b0.downsample is None:
+            raise ValueError("the last decoder block has no 1x1 downsample branch to wire through")
+        ds = b0.downsample[0].kernel  # [416, 384]
+        ds[:, 0:2] = 0.0
+        ds[up_planes + 0, 0] = 1.0
+        ds[up_planes + 1, 1] = 1.0
+        for blk in last_block:
+            blk.conv2.kernel[:, :, 0:2] = 0.0
+        fin = model.final.kernel  # [384, 256]
+        fin[:, 0:2] = 0.0
+        fin[0, 0] = 1.0
+        fin[1, 1] = 1.0
+        model.final.bias[0, 0:2] = 0.0
+        r0 = model.regression[0].linear  # weight [1024, 256]
+        r0.weight[0:2, :] = 0.0
+        r0.weight[0, 0] = 1.0
+        r0.weight[1, 1] = 1.0
+        r0.bias[0:2] = 0.0
+        r2 = model.regression[2].linear  # weight [classes, 1024]
+        r2.weight.zero_()
+        r2.weight[2, 0] = gain
+        r2.weight[1, 1] = gain
+        r2.bias.copy_(torch.tensor([0.0, -1.0, -1.0])[: r2.bias.numel()])
+    return model

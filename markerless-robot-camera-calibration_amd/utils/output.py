@@ -44,7 +44,10 @@ def get_key_point_predictions(logits, conf_th=0.999):
 def get_pred_center(out, coords, ee_r=0.03, q=None):
     """mean of the 8 highest-vote points, optionally moved by (-ee_r, 0, 0) rotated by the quaternion q (w first)
     (utils/output.py:45-64)."""
-    sel = out[:, 1].sort(descending=True)[1][:8]
+    if torch.is_tensor(out) and out.is_cuda:
+        sel = topk_indices(out[:, 1], 8)  # one selection pass instead of a full sort of every point's vote
+    else:
+        sel = out[:, 1].sort(descending=True)[1][:8]
     pred_center = coords[sel.cpu().numpy()].mean(axis=0)
     if q is not None:
         from .transformation import get_quaternion_rotation_matrix_torch
@@ -57,6 +60,25 @@ def get_pred_center(out, coords, ee_r=0.03, q=None):
             offset_rotated = offset_rotated.cpu().numpy()
         pred_center += offset_rotated
     return pred_center
+
+
+def topk_indices(column, k):
+    """rows of the k largest entries of a float32 CUDA column (any stride), largest first, ties to the lower row - the
+    `column.sort(descending=True)[1][:k]` of utils/output.py:47 as a selection (sv_topk_indices), int64 CUDA [min(k, n)]."""
+    from ctypes import c_int, c_int64, c_size_t
+
+    from .._lib import call, load, ptr, stream_ptr
+
+    x = column.detach()
+    if x.dtype != torch.float32:
+        x = x.to(torch.float32)
+    n = x.shape[0]
+    nbytes = load().sv_topk_workspace_bytes(c_int64(n), c_int(k))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    idx = torch.empty(k, dtype=torch.int64, device=x.device)
+    call("sv_topk_indices", ptr(x), c_int64(x.stride(0) if n > 1 else 1), c_int64(n), c_int(k), ptr(ws), c_size_t(nbytes), ptr(idx),
+         stream_ptr())
+    return idx[: min(k, n)]
 
 
 def select_equal(values, value):
