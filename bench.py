@@ -445,13 +445,15 @@ def launcher_selftest(args, world, rank):
     assert produced == [2 * s_ for s_ in seeds]
     reps = [0.001 * (rank + 1) * (1 + 0.1 * r) for r in range(args.repeats)]
     agg = gather_metrics({"frames": len(seeds), "elapsed": reps[0], "confusion": np.eye(3, dtype=np.int64),
-                          "seed_sum": int(sum(seeds)), "elapsed_repeats": reps}, device="cpu")
+                          "seed_sum": int(sum(seeds)), "elapsed_repeats": reps,
+                          "per_rank": {"host_prepare_ms": 1.5 + rank, "pinned_cores": pin.get("cores") or 0}}, device="cpu")
     if rank == 0:
         print(json.dumps({"metric": "launcher selftest (no GPU work)", "n_gpus": world, "steps": args.steps,
                           "scaling": "strong" if args.total_frames > 0 else "weak",
                           "frames": agg["frames"], "per_rank_frames": agg["per_rank_frames"],
                           "seed_sum": agg["seed_sum"], "elapsed_max": agg["elapsed_max"],
                           "elapsed_repeats_max": agg["elapsed_repeats_max"], "pinned_cores": pin.get("cores"),
+                          "per_rank_elapsed": agg["per_rank_elapsed"], "per_rank": agg["per_rank"],
                           "selftest": True}), flush=True)
     if world > 1:
         dist.barrier()
@@ -842,7 +844,10 @@ def main():
         with torch.no_grad():
             rec = strong_scaling_block(model, device, rank, world, args.total_frames, args.streams, src_threads, barrier)
         agg = gather_metrics({"frames": rec["frames"], "elapsed": rec["elapsed"], "confusion": np.diag(rec["hist"]),
-                              "seed_sum": rec["seed_sum"]}, device=device if backend == "nccl" else "cpu")
+                              "seed_sum": rec["seed_sum"],
+                              "per_rank": dict({f"host_{k}_ms": v for k, v in rec["host_ms_per_frame"].items()},
+                                               pinned_cores=pin.get("cores") or 0)},
+                             device=device if backend == "nccl" else "cpu")
         if rank == 0:
             t_max = agg["elapsed_max"]
             line = {"metric": "point-cloud frames/sec at 200k pts/frame", "value": round(agg["frames"] / t_max, 3),
@@ -856,6 +861,8 @@ def main():
                                "total_frames": args.total_frames, "per_rank_frames": agg["per_rank_frames"],
                                "points_per_frame": POINTS, "label_histogram": [int(v) for v in np.diag(agg["confusion"])],
                                "host_ms_per_frame_rank0": rec["host_ms_per_frame"], "host_placement": pin,
+                               "per_rank_elapsed_s": [round(x, 4) for x in agg["per_rank_elapsed"]],
+                               "per_rank": {k: [round(x, 3) for x in v] for k, v in agg["per_rank"].items()},
                                "parallelism": f"frame-sharded x{world} (rank r: seeds r, r + {world}, ...), one all_gather "
                                               "of metrics"},
                     "roofline": None, "cpu_baseline": base}
@@ -958,8 +965,13 @@ def main():
 
     # the run's ONE collective: all_gather of a small per-rank record (RCCL over xGMI when world > 1)
     h = hist.cpu().numpy()
+    per_rank = {"median_repeat_s": _median(elapsed_list), "pinned_cores": pin.get("cores") or 0}
+    if strong:
+        per_rank.update({"strong_elapsed_s": strong["elapsed"], "strong_frames": strong["frames"]})
+        per_rank.update({f"strong_host_{k}_ms": v for k, v in strong["host_ms_per_frame"].items()})
     rec = {"frames": args.steps * args.frames_per_step, "elapsed": elapsed, "confusion": np.diag(h), "seed_sum": voxels,
-           "elapsed_repeats": elapsed_list + ([strong["elapsed"], float(strong["frames"])] if strong else [])}
+           "elapsed_repeats": elapsed_list + ([strong["elapsed"], float(strong["frames"])] if strong else []),
+           "per_rank": per_rank}
     agg = gather_metrics(rec, device=device if backend == "nccl" else "cpu")
     reps_max = agg["elapsed_repeats_max"][:len(elapsed_list)]
     t_med = _median(reps_max)
@@ -1063,6 +1075,7 @@ def main():
                                       f"{args.streams} compute stream(s) alternating between frames"},
             "roofline": roofline,
             "kernels_warmup": kernels,
+            "per_rank": {k: [round(x, 4) for x in v] for k, v in agg["per_rank"].items() if not k.startswith("strong_")},
         }
         if strong is not None:
             extra = agg["elapsed_repeats_max"][len(elapsed_list):]
@@ -1074,7 +1087,10 @@ def main():
                 "scaling": "strong", "total_frames": args.strong_frames, "value": round(args.strong_frames / t_strong, 3),
                 "unit": "frames/s", "seconds": round(t_strong, 3), "frames_rank0": strong["frames"],
                 "source_threads_per_rank": src_threads, "host_ms_per_frame_rank0": strong["host_ms_per_frame"],
-                "note": "same total job at every N: value(N) / value(1) is the strong-scaling speed-up"}
+                "per_rank": {k[len("strong_"):]: [round(x, 3) for x in v] for k, v in agg["per_rank"].items()
+                             if k.startswith("strong_")},
+                "note": "same total job at every N: value(N) / value(1) is the strong-scaling speed-up; per_rank: every "
+                        "rank's own elapsed time, frames and host milliseconds per frame and phase"}
         if hbm_layers is not None:
             line["hbm_bound_layers"] = hbm_layers
         if batched is not None:

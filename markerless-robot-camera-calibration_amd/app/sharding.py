@@ -94,12 +94,17 @@ _FIELDS = 4  # frames, elapsed, seed_sum, ncls
 
 def gather_metrics(record, device="cuda", num_classes=3):
     """record: {"frames": int, "elapsed": float, "confusion": int64[num_classes, num_classes], "seed_sum": int,
-    "elapsed_repeats": [float, ...] (optional: the timed region repeated R times; same R on every rank)}.
-    ONE all_gather of a float64 vector per rank; returns the aggregate on every rank."""
+    "elapsed_repeats": [float, ...] (optional: the timed region repeated R times; same R on every rank),
+    "per_rank": {name: float} (optional: figures reported rank by rank - elapsed, host milliseconds per phase, pinned
+    cores ...; the same names on every rank)}.
+    ONE all_gather of a float64 vector per rank; returns the aggregate on every rank, `per_rank` as {name: [value of
+    rank 0, rank 1, ...]} so that a slow or host-bound rank can be told from the line."""
     import torch.distributed as dist
 
     reps = [float(x) for x in record.get("elapsed_repeats", [])]
-    vec = torch.zeros(_FIELDS + num_classes * num_classes + len(reps), dtype=torch.float64, device=device)
+    names = sorted(record.get("per_rank", {}))
+    extra = [float(record["per_rank"][k]) for k in names]
+    vec = torch.zeros(_FIELDS + num_classes * num_classes + len(reps) + len(extra), dtype=torch.float64, device=device)
     vec[0] = record["frames"]
     vec[1] = record["elapsed"]
     vec[2] = record.get("seed_sum", 0)
@@ -107,7 +112,9 @@ def gather_metrics(record, device="cuda", num_classes=3):
     nc2 = num_classes * num_classes
     vec[_FIELDS:_FIELDS + nc2] = torch.as_tensor(np.asarray(record["confusion"], dtype=np.float64).reshape(-1))
     if reps:
-        vec[_FIELDS + nc2:] = torch.as_tensor(reps, dtype=torch.float64)
+        vec[_FIELDS + nc2:_FIELDS + nc2 + len(reps)] = torch.as_tensor(reps, dtype=torch.float64)
+    if extra:
+        vec[_FIELDS + nc2 + len(reps):] = torch.as_tensor(extra, dtype=torch.float64)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         parts = [torch.zeros_like(vec) for _ in range(dist.get_world_size())]
         dist.all_gather(parts, vec)
@@ -121,7 +128,9 @@ def gather_metrics(record, device="cuda", num_classes=3):
         "seed_sum": int(allv[:, 2].sum()),
         "confusion": allv[:, _FIELDS:_FIELDS + nc2].sum(axis=0).reshape(num_classes, num_classes).astype(np.int64),
         # per repeat: the slowest rank's time (the job's time for that repeat)
-        "elapsed_repeats_max": [float(x) for x in allv[:, _FIELDS + nc2:].max(axis=0)],
+        "elapsed_repeats_max": [float(x) for x in allv[:, _FIELDS + nc2:_FIELDS + nc2 + len(reps)].max(axis=0)],
+        "per_rank_elapsed": [float(x) for x in allv[:, 1]],
+        "per_rank": {k: [float(x) for x in allv[:, _FIELDS + nc2 + len(reps) + i]] for i, k in enumerate(names)},
     }
 
 

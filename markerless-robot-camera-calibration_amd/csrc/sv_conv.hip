@@ -19,6 +19,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
+#include <algorithm>
 #include <vector>
 
 #include "sv_common.h"
@@ -1100,11 +1101,250 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(ConvParams p) {
   epilogue_buffered<1, NT, true>(p, acc, row0, lq, NT * li, o_pre);
 }
 
+// ---- the thin layers with the layer's WHOLE weight tensor resident in LDS (round 4; conv_thin_kernel above is kept behind
+//      SV_THIN_VARIANT for A/B).  What the counters said about conv_thin_kernel at 88k voxels (profiles/r04_pmc_thin_*.txt):
+//      matrix pipe 29 % busy, waves 66 % of their life stalled at issue, and the CU's vector-memory pipe (TCP) handling
+//      17.4 M cache accesses per launch = 68 k cycles per CU of a 110 k-cycle launch - two thirds of them WEIGHT loads: every
+//      wave fetched the 4 KB weight block of every offset it visited through L1 (251 MB per launch for a 110 KB tensor),
+//      and a wave alone on its SIMD waited an L2 round trip per offset for them (one offset of look-ahead is shorter).
+//      27 x 32 x 32 floats are 110 KB: they fit the CU's 160 KB LDS beside the waves' neighbour tables.  So: ONE workgroup
+//      of 16 waves per CU stages the weights once (coalesced float4, ~1 us), then every wave walks 16-row sub-tiles
+//      (longest plan tiles first, wave w of workgroup b takes sub-tiles b + G w, b + G (w + 16), ...) exactly as
+//      conv_thin_kernel does - compacted offset list, D gathers in flight, lane-group transposes, the (k, c) chain order
+//      and therefore every result bit - with its B operands read from LDS (one conflict-free ds_read_b64 per k-step) and
+//      only the row gathers left on the vector-memory path.
+template <int CIN, int COUT, int D, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void conv_thin_lds_kernel(ConvParams p, int n_sub) {
+  constexpr int NT = COUT / 16, KS = CIN / 4, G4 = CIN / 16;
+  constexpr int ST = 32 * 16 / 64;  // table entries per lane (K <= 32)
+  static_assert(CIN % 16 == 0 && COUT % 16 == 0 && NT >= 1 && NT <= 4, "shape");
+  typedef float bvec_t __attribute__((ext_vector_type(NT)));
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ int q_head;  // the workgroup's tile queue: next unassigned position of its tile list
+  const int K = p.K;
+  float* w_s = lds;                                     // [K][CIN][COUT]
+  int* idx_all = (int*)(lds + (size_t)K * CIN * COUT);  // [WAVES][32 * 16] neighbour rows of a wave's sub-tile (byte offsets)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lq = lane >> 4;
+  // SV_THIN_TRACE experiments: per-wave cycle stamps {start, weights staged, first tile: table staged / loop done / stored,
+  // end, tiles, offsets of the first tile}
+  unsigned long long tr[6] = {0, 0, 0, 0, 0, 0}, tr_it[3] = {0, 0, 0};
+  int tr_tiles = 0, tr_nact = 0;
+  if (p.trace) tr[0] = __builtin_amdgcn_s_memtime();
+  if (tid == 0) q_head = WAVES;  // positions 0 .. WAVES-1 are the waves' first tiles
+  // The workgroup's tile list: position i = sub-tile blockIdx.x + gridDim.x * i in LONGEST-FIRST order (plan tile
+  // tile_order[t / 8], its sub-tile t % 8): every workgroup gets the same mix of long and short tiles; inside the workgroup
+  // the waves PULL positions from q_head (an LDS atomic: no global counter to reset), so a CU's sixteen waves finish within
+  // one tile of each other.
+  struct Tile {
+    int t128, sub;   // wave-uniform (scalar registers)
+    int perm[1][4];
+    uint32_t sm;     // lane k: the tile's submask word of offset k
+    int n_st[ST];    // neighbour rows (lane + 64 it: offset e / 16, row e % 16)
+  };
+  auto fetch = [&](int pos, Tile& T) -> bool {  // requests a tile's table; nothing waits here
+    const int t = (int)blockIdx.x + (int)gridDim.x * pos;
+    if (t >= n_sub) return false;
+    T.t128 = __builtin_amdgcn_readfirstlane(p.tile_order ? p.tile_order[t >> 3] : (t >> 3));
+    T.sub = t & 7;
+    const int64_t row0 = (int64_t)T.t128 * PLAN_TILE + T.sub * 16;
+    load_perm_rows<1>(p, row0, lq, T.perm);
+    T.sm = lane < K ? p.submask[(int64_t)T.t128 * K + lane] : 0u;
+#pragma unroll
+    for (int it = 0; it < ST; ++it) {
+      const int e = lane + 64 * it;
+      T.n_st[it] = e < K * 16 ? p.nbr_s[(int64_t)(e >> 4) * p.Vpad + row0 + (e & 15)] : -1;
+    }
+    return true;
+  };
+  Tile cur;
+  bool have = fetch(wid, cur);  // on its way while the weights are staged
+  // ---- the layer's weights, once per workgroup
+  {
+    const float4* src = (const float4*)p.W;
+    float4* dst = (float4*)w_s;
+    const int n4 = K * CIN * COUT / 4;
+    for (int i = tid; i < n4; i += WAVES * 64) dst[i] = src[i];
+  }
+  __syncthreads();
+  if (p.trace) tr[1] = __builtin_amdgcn_s_memtime();
+  int* idx_s = idx_all + wid * (32 * 16);
+  const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+  const float* w_lane = w_s + lq * COUT + NT * li;
+  while (have) {
+    // ---- this tile's table into LDS as byte offsets (absent: beyond the extent -> the gather returns zeros)
+#pragma unroll
+    for (int it = 0; it < ST; ++it) {
+      const int e = lane + 64 * it;
+      if (e < K * 16) idx_s[e] = (int)(cur.n_st[it] >= 0 ? (uint32_t)cur.n_st[it] * (uint32_t)(p.in_ld * 4) : BUF_ABSENT);
+    }
+    // active offsets of the sub-tile: a scalar bit mask walked with bit scans (no list in memory; two cursors: the gathers
+    // run D offsets ahead of the matrix ops, the weight reads one)
+    const uint32_t amask = (uint32_t)__ballot((cur.sm >> cur.sub) & 1u);
+    const int nact = __builtin_popcount(amask);
+    const int64_t row0 = (int64_t)cur.t128 * PLAN_TILE + cur.sub * 16;
+    int o_pre[1][4] = {{cur.perm[0][0], cur.perm[0][1], cur.perm[0][2], cur.perm[0][3]}};
+    __builtin_amdgcn_wave_barrier();
+    if (p.trace && tr_tiles == 0) {
+      tr[2] = __builtin_amdgcn_s_memtime();
+      tr_nact = nact;
+    }
+    f32x4 acc[1][NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[0][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 g[D][G4];
+    bvec_t b[2][KS];
+    uint32_t g_rest = amask, w_rest = amask;
+    const int k_last = amask ? 31 - __builtin_clz(amask) : 0;
+    auto issue = [&](float4 (&dst)[G4]) {  // gathers of the next offset of the gather cursor (past the end: zeros, no access)
+      const bool any = g_rest != 0u;
+      const int k = any ? __builtin_ctz(g_rest) : k_last;
+      g_rest &= g_rest - 1u;
+      const uint32_t off = any ? (uint32_t)idx_s[k * 16 + li] : BUF_ABSENT;
+#pragma unroll
+      for (int jj = 0; jj < G4; ++jj) {
+        const f32x4 v = buffer_load_floats<4>(rsrc_in, off + 16u * (uint32_t)lq, 64u * (uint32_t)jj);
+        dst[jj] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    };
+    auto load_w = [&](bvec_t (&dst)[KS]) {  // B operands of the weight cursor's next offset, from LDS
+      const int k = w_rest ? __builtin_ctz(w_rest) : k_last;
+      w_rest &= w_rest - 1u;
+      const float* wk = w_lane + k * (CIN * COUT);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) dst[ks] = *(const bvec_t*)(wk + 4 * ks * COUT);
+    };
+    auto compute = [&](float4 (&a)[G4], bvec_t (&w)[KS]) {
+#pragma unroll
+      for (int jj = 0; jj < G4; ++jj) {
+        float am[4] = {a[jj].x, a[jj].y, a[jj].z, a[jj].w};
+        transpose4x4_lanegroups(am[0], am[1], am[2], am[3]);  // [m]: channel 16 jj + 4 m + lq of row li
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[m], w[4 * jj + m][n], acc[0][n], 0, 0, 0);
+      }
+    };
+    // the first gathers go out BEFORE the next tile's table is requested: vmcnt counts in order, so the first matrix ops
+    // wait for their own rows only
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue(g[d]);
+    load_w(b[0]);
+    // ---- pull the next tile and request its table: it arrives while this tile is multiplied
+    Tile nxt;
+    int pos = 0;
+    if (lane == 0) pos = __hip_atomic_fetch_add(&q_head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    pos = __builtin_amdgcn_readfirstlane(pos);
+    const bool have_nxt = fetch(pos, nxt);
+    if (nact > 0) {
+      constexpr int U = (D % 2 == 0) ? D : 2 * D;
+      for (int j0 = 0; j0 < nact; j0 += U) {
+        if (p.trace && tr_tiles == 0 && j0 < 3 * U) tr_it[j0 / U] = __builtin_amdgcn_s_memtime() + (unsigned long long)(acc[0][0][0] == 12345.678f);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          load_w(b[(u + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);  // the weight reads of the NEXT offset go out before this offset's matrix ops
+          compute(g[u % D], b[u & 1]);
+          issue(g[u % D]);
+        }
+      }
+    }
+    if (p.trace && tr_tiles == 0) {
+      // the accumulators are the loop's last results: reading one orders the stamp behind the matrix ops
+      tr[3] = __builtin_amdgcn_s_memtime() + (unsigned long long)(acc[0][0][0] == 12345.678f);
+    }
+    epilogue_buffered<1, NT, true>(p, acc, row0, lq, NT * li, o_pre);
+    __builtin_amdgcn_wave_barrier();  // the next sub-tile's table overwrites this one's
+    if (p.trace && tr_tiles == 0) tr[4] = __builtin_amdgcn_s_memtime();
+    ++tr_tiles;
+    have = have_nxt;
+    if (have_nxt) cur = nxt;
+  }
+  if (p.trace && lane == 0) {
+    tr[5] = __builtin_amdgcn_s_memtime();
+    unsigned long long* o = p.trace + ((size_t)blockIdx.x * WAVES + wid) * 12;
+    for (int i = 0; i < 6; ++i) o[i] = tr[i];
+    o[6] = (unsigned long long)tr_tiles;
+    o[7] = (unsigned long long)tr_nact;
+    for (int i = 0; i < 3; ++i) o[8 + i] = tr_it[i];
+  }
+}
+
+static int launch_conv_thin_lds(const ConvParams& p, hipStream_t stream) {
+  constexpr int WAVES = 16;
+  static int n_cu = 0;
+  const size_t lds = ((size_t)p.K * 32 * 32 + (size_t)WAVES * (32 * 16)) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    SV_HIP(hipGetDevice(&dev));
+    SV_HIP(hipGetDeviceProperties(&prop, dev));
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    SV_HIP(hipFuncSetAttribute((const void*)conv_thin_lds_kernel<32, 32, 4, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(((size_t)27 * 32 * 32 + (size_t)WAVES * (32 * 16 + 32)) * sizeof(float))));
+    attr_set = true;
+  }
+  const int n_sub = (int)(p.Vpad / 16);
+  const int grid = n_sub < n_cu ? n_sub : n_cu;
+  static const bool trace = getenv("SV_THIN_TRACE") != nullptr;  // experiments only: phase stamps of one launch to stderr
+  ConvParams q = p;
+  q.trace = nullptr;
+  if (trace) {
+    SV_HIP(hipMalloc((void**)&q.trace, (size_t)grid * WAVES * 12 * sizeof(unsigned long long)));
+    SV_HIP(hipMemsetAsync(q.trace, 0, (size_t)grid * WAVES * 12 * sizeof(unsigned long long), stream));
+  }
+  hipLaunchKernelGGL((conv_thin_lds_kernel<32, 32, 4, WAVES>), dim3((unsigned)grid), dim3(WAVES * 64), lds, stream, q, n_sub);
+  note_instance("conv_thin_lds_kernel<32, 32>|fast=1,ring=0,full=1");
+  SV_LAUNCH_CHECK();
+  if (trace) {
+    std::vector<unsigned long long> h((size_t)grid * WAVES * 12);
+    SV_HIP(hipStreamSynchronize(stream));
+    SV_HIP(hipMemcpy(h.data(), q.trace, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    SV_HIP(hipFree(q.trace));
+    std::vector<double> stage, table, loop, store, life, per_off, it01, it12, pre;
+    unsigned long long t_min = ~0ull, t_max = 0;
+    for (size_t w = 0; w < (size_t)grid * WAVES; ++w) {
+      const unsigned long long* o = &h[w * 12];
+      if (!o[0]) continue;
+      if (o[8] && o[9] && o[10]) {
+        pre.push_back((double)(o[8] - o[2]));
+        it01.push_back((double)(o[9] - o[8]));
+        it12.push_back((double)(o[10] - o[9]));
+      }
+      t_min = o[0] < t_min ? o[0] : t_min;
+      t_max = o[5] > t_max ? o[5] : t_max;
+      stage.push_back((double)(o[1] - o[0]));
+      life.push_back((double)(o[5] - o[0]));
+      if (o[6]) {
+        table.push_back((double)(o[2] - o[1]));
+        loop.push_back((double)(o[3] - o[2]));
+        store.push_back((double)(o[4] - o[3]));
+        if (o[7]) per_off.push_back((double)(o[3] - o[2]) / (double)o[7]);
+      }
+    }
+    auto med = [](std::vector<double>& v) {
+      if (v.empty()) return 0.0;
+      std::sort(v.begin(), v.end());
+      return v[v.size() / 2];
+    };
+    fprintf(stderr, "[thin trace] K=%d n_sub=%d grid=%d span %llu cyc | median cycles: weights staged %.0f, first tile: table %.0f, loop %.0f "
+            "(%.0f per offset; table staged -> loop %.0f, first 4 offsets %.0f, next 4 %.0f), store %.0f, wave life %.0f\n", p.K, n_sub,
+            grid, t_max - t_min, med(stage), med(table), med(loop), med(per_off), med(pre), med(it01), med(it12), med(store), med(life));
+  }
+  return SV_OK;
+}
+
 static int launch_conv_thin(const ConvParams& p, hipStream_t stream) {
   // one 16-row sub-tile per wave, four offsets in flight: 24 us for block1's 32->32 at level 1 (26.5k voxels) against 35 us
   // on the LDS-staged fused-offset tile, 49 against 84 us at 88k voxels (2.65 TB/s on algorithmic gather-bytes).  Two
   // sub-tiles per wave (shared weight registers) 27-28 / 48 us, three or six offsets in flight 26 / 51-54 us.
-  static const int variant = getenv("SV_THIN_VARIANT") ? atoi(getenv("SV_THIN_VARIANT")) : 0;  // experiments only
+  static const int variant = getenv("SV_THIN_VARIANT") ? atoi(getenv("SV_THIN_VARIANT")) : -1;  // experiments only
+  // default (round 4): the layer's weights resident in LDS, one 16-wave workgroup per CU (conv_thin_lds_kernel)
+  if (variant < 0 && p.K <= 27 && (((uintptr_t)p.W) & 15) == 0) return launch_conv_thin_lds(p, stream);
   const dim3 g1((unsigned)(p.Vpad / 64)), g2((unsigned)(p.Vpad / 64), 2);
   switch (variant) {
     case 1: hipLaunchKernelGGL((conv_thin_kernel<32, 32, 1, 4, 2>), g2, dim3(256), 0, stream, p); break;

@@ -100,6 +100,12 @@ def test_strong_scaling_mode_partitions_a_fixed_job():
         assert len(out["elapsed_repeats_max"]) == 5  # per repeat: the slowest rank's time
         assert abs(out["elapsed_repeats_max"][0] - 0.001 * world) < 1e-12
         assert out["pinned_cores"] >= 1
+        # rank-by-rank figures travel in the same gather: every rank's own elapsed time, host time and core count, so a
+        # slow or host-bound rank is identifiable from rank 0's line
+        assert len(out["per_rank_elapsed"]) == world
+        assert all(abs(out["per_rank_elapsed"][r] - 0.001 * (r + 1)) < 1e-12 for r in range(world))
+        assert out["per_rank"]["host_prepare_ms"] == [1.5 + r for r in range(world)]
+        assert len(out["per_rank"]["pinned_cores"]) == world and min(out["per_rank"]["pinned_cores"]) >= 1
 
 
 def test_rank_pinning_from_sysfs_topology(tmp_path):
