@@ -401,11 +401,14 @@ def hbm_bound_layers(model, device, iters=60):
             s0, b0 = model.bn0.folded()
             s1, b1 = blk.norm1.folded()
             f1 = torch.randn(V1, 32, device=device)
+            f0 = torch.randn(V0, 32, device=device)
             f1024 = torch.randn(V0, 1024, device=device)
             head = model.regression[2]
             cases = {
                 "conv0 3->32 k27 (level 0)": (x.F, model.conv0p1s1.weight3().detach(), p0, V0, s0, b0),
                 "block1 32->32 k27 (level 1)": (f1, blk.conv1.weight3().detach(), p1, V1, s1, b1),
+                # the same layer shape on the level-0 map: the north_star's "gather at 80k active voxels"
+                "32->32 k27 on the level-0 map": (f0, blk.conv1.weight3().detach(), p0, V0, s1, b1),
                 "regression.2 1024->3 (level 0)": (f1024, head.weight3(), None, V0, None, head.linear.bias.detach()),
             }
             for name, (f, w, plan, V, sc, sh) in cases.items():
@@ -420,7 +423,7 @@ def hbm_bound_layers(model, device, iters=60):
                                    "timing": "hipGraph replay" if graph_us is not None else "eager series",
                                    "algorithmic_MB": round(gb * 1e3, 2), "GBps": round(gb / (us * 1e-6), 1),
                                    "frac_of_hbm_peak": round(gb / (us * 1e-6) / PEAK_HBM_GBS, 4)}
-            del frame, field, x, f1, f1024
+            del frame, field, x, f1, f0, f1024
     return out
 
 

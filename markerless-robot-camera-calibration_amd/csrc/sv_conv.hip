@@ -1113,7 +1113,7 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(ConvParams p) {
 //      conv_thin_kernel does - compacted offset list, D gathers in flight, lane-group transposes, the (k, c) chain order
 //      and therefore every result bit - with its B operands read from LDS (one conflict-free ds_read_b64 per k-step) and
 //      only the row gathers left on the vector-memory path.
-template <int CIN, int COUT, int D, int WAVES>
+template <int CIN, int COUT, int D, int WAVES, bool PREFETCH>
 __global__ __launch_bounds__(WAVES * 64) void conv_thin_lds_kernel(ConvParams p, int n_sub) {
   constexpr int NT = COUT / 16, KS = CIN / 4, G4 = CIN / 16;
   constexpr int ST = 32 * 16 / 64;  // table entries per lane (K <= 32)
@@ -1160,7 +1160,8 @@ __global__ __launch_bounds__(WAVES * 64) void conv_thin_lds_kernel(ConvParams p,
     return true;
   };
   Tile cur;
-  bool have = fetch(wid, cur);  // on its way while the weights are staged
+  bool have = false;
+  if (PREFETCH) have = fetch(wid, cur);  // on its way while the weights are staged
   // ---- the layer's weights, once per workgroup
   {
     const float4* src = (const float4*)p.W;
@@ -1170,6 +1171,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_thin_lds_kernel(ConvParams p,
   }
   __syncthreads();
   if (p.trace) tr[1] = __builtin_amdgcn_s_memtime();
+  if (!PREFETCH) have = fetch(wid, cur);
   int* idx_s = idx_all + wid * (32 * 16);
   const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
   const float* w_lane = w_s + lq * COUT + NT * li;
@@ -1220,7 +1222,9 @@ __global__ __launch_bounds__(WAVES * 64) void conv_thin_lds_kernel(ConvParams p,
 #pragma unroll
       for (int jj = 0; jj < G4; ++jj) {
         float am[4] = {a[jj].x, a[jj].y, a[jj].z, a[jj].w};
+#if !defined(SV_THIN_ABL) || !(SV_THIN_ABL & 4)
         transpose4x4_lanegroups(am[0], am[1], am[2], am[3]);  // [m]: channel 16 jj + 4 m + lq of row li
+#endif
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -1236,19 +1240,25 @@ __global__ __launch_bounds__(WAVES * 64) void conv_thin_lds_kernel(ConvParams p,
     // ---- pull the next tile and request its table: it arrives while this tile is multiplied
     Tile nxt;
     int pos = 0;
-    if (lane == 0) pos = __hip_atomic_fetch_add(&q_head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    pos = __builtin_amdgcn_readfirstlane(pos);
-    const bool have_nxt = fetch(pos, nxt);
+    bool have_nxt = false;
+    if (PREFETCH) {
+      if (lane == 0) pos = __hip_atomic_fetch_add(&q_head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      pos = __builtin_amdgcn_readfirstlane(pos);
+      have_nxt = fetch(pos, nxt);
+    }
     if (nact > 0) {
       constexpr int U = (D % 2 == 0) ? D : 2 * D;
       for (int j0 = 0; j0 < nact; j0 += U) {
         if (p.trace && tr_tiles == 0 && j0 < 3 * U) tr_it[j0 / U] = __builtin_amdgcn_s_memtime() + (unsigned long long)(acc[0][0][0] == 12345.678f);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          load_w(b[(u + 1) & 1]);
+#ifndef SV_THIN_ABL  // timing-only ablations (results WRONG): 1 = no gathers in the loop, 2 = no weight reads, 4 = no transposes
+#define SV_THIN_ABL 0
+#endif
+          if (!(SV_THIN_ABL & 2)) load_w(b[(u + 1) & 1]);
           __builtin_amdgcn_sched_barrier(0);  // the weight reads of the NEXT offset go out before this offset's matrix ops
-          compute(g[u % D], b[u & 1]);
-          issue(g[u % D]);
+          compute(g[u % D], b[(SV_THIN_ABL & 2) ? 0 : (u & 1)]);
+          if (!(SV_THIN_ABL & 1)) issue(g[u % D]);
         }
       }
     }
@@ -1260,6 +1270,11 @@ __global__ __launch_bounds__(WAVES * 64) void conv_thin_lds_kernel(ConvParams p,
     __builtin_amdgcn_wave_barrier();  // the next sub-tile's table overwrites this one's
     if (p.trace && tr_tiles == 0) tr[4] = __builtin_amdgcn_s_memtime();
     ++tr_tiles;
+    if (!PREFETCH) {
+      if (lane == 0) pos = __hip_atomic_fetch_add(&q_head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      pos = __builtin_amdgcn_readfirstlane(pos);
+      have_nxt = fetch(pos, nxt);
+    }
     have = have_nxt;
     if (have_nxt) cur = nxt;
   }
@@ -1273,8 +1288,8 @@ __global__ __launch_bounds__(WAVES * 64) void conv_thin_lds_kernel(ConvParams p,
   }
 }
 
-static int launch_conv_thin_lds(const ConvParams& p, hipStream_t stream) {
-  constexpr int WAVES = 16;
+template <int D, int WAVES, bool PREFETCH>
+static int launch_conv_thin_lds_t(const ConvParams& p, hipStream_t stream) {
   static int n_cu = 0;
   const size_t lds = ((size_t)p.K * 32 * 32 + (size_t)WAVES * (32 * 16)) * sizeof(float);
   static bool attr_set = false;
@@ -1284,8 +1299,8 @@ static int launch_conv_thin_lds(const ConvParams& p, hipStream_t stream) {
     SV_HIP(hipGetDevice(&dev));
     SV_HIP(hipGetDeviceProperties(&prop, dev));
     n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    SV_HIP(hipFuncSetAttribute((const void*)conv_thin_lds_kernel<32, 32, 4, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)(((size_t)27 * 32 * 32 + (size_t)WAVES * (32 * 16 + 32)) * sizeof(float))));
+    SV_HIP(hipFuncSetAttribute((const void*)conv_thin_lds_kernel<32, 32, D, WAVES, PREFETCH>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(((size_t)27 * 32 * 32 + (size_t)WAVES * (32 * 16)) * sizeof(float))));
     attr_set = true;
   }
   const int n_sub = (int)(p.Vpad / 16);
@@ -1297,7 +1312,7 @@ static int launch_conv_thin_lds(const ConvParams& p, hipStream_t stream) {
     SV_HIP(hipMalloc((void**)&q.trace, (size_t)grid * WAVES * 12 * sizeof(unsigned long long)));
     SV_HIP(hipMemsetAsync(q.trace, 0, (size_t)grid * WAVES * 12 * sizeof(unsigned long long), stream));
   }
-  hipLaunchKernelGGL((conv_thin_lds_kernel<32, 32, 4, WAVES>), dim3((unsigned)grid), dim3(WAVES * 64), lds, stream, q, n_sub);
+  hipLaunchKernelGGL((conv_thin_lds_kernel<32, 32, D, WAVES, PREFETCH>), dim3((unsigned)grid), dim3(WAVES * 64), lds, stream, q, n_sub);
   note_instance("conv_thin_lds_kernel<32, 32>|fast=1,ring=0,full=1");
   SV_LAUNCH_CHECK();
   if (trace) {
@@ -1306,7 +1321,6 @@ static int launch_conv_thin_lds(const ConvParams& p, hipStream_t stream) {
     SV_HIP(hipMemcpy(h.data(), q.trace, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     SV_HIP(hipFree(q.trace));
     std::vector<double> stage, table, loop, store, life, per_off, it01, it12, pre;
-    unsigned long long t_min = ~0ull, t_max = 0;
     for (size_t w = 0; w < (size_t)grid * WAVES; ++w) {
       const unsigned long long* o = &h[w * 12];
       if (!o[0]) continue;
@@ -1315,8 +1329,6 @@ static int launch_conv_thin_lds(const ConvParams& p, hipStream_t stream) {
         it01.push_back((double)(o[9] - o[8]));
         it12.push_back((double)(o[10] - o[9]));
       }
-      t_min = o[0] < t_min ? o[0] : t_min;
-      t_max = o[5] > t_max ? o[5] : t_max;
       stage.push_back((double)(o[1] - o[0]));
       life.push_back((double)(o[5] - o[0]));
       if (o[6]) {
@@ -1331,11 +1343,23 @@ static int launch_conv_thin_lds(const ConvParams& p, hipStream_t stream) {
       std::sort(v.begin(), v.end());
       return v[v.size() / 2];
     };
-    fprintf(stderr, "[thin trace] K=%d n_sub=%d grid=%d span %llu cyc | median cycles: weights staged %.0f, first tile: table %.0f, loop %.0f "
+    fprintf(stderr, "[thin trace] K=%d n_sub=%d grid=%d | median cycles: weights staged %.0f, first tile: table %.0f, loop %.0f "
             "(%.0f per offset; table staged -> loop %.0f, first 4 offsets %.0f, next 4 %.0f), store %.0f, wave life %.0f\n", p.K, n_sub,
-            grid, t_max - t_min, med(stage), med(table), med(loop), med(per_off), med(pre), med(it01), med(it12), med(store), med(life));
+            grid, med(stage), med(table), med(loop), med(per_off), med(pre), med(it01), med(it12), med(store), med(life));
   }
   return SV_OK;
+}
+
+static int launch_conv_thin_lds(const ConvParams& p, hipStream_t stream, int variant) {
+  // <gathers in flight, waves per workgroup, next tile's table requested during the current tile>: measured at 88k / 26k voxels
+  // (tools/hbm_layers_microbench.py, profiles/r04_thin_variants.txt): <2,16,no> 33.9 / 19.3 us (126 VGPRs, no spills),
+  // <2,16,yes> 36.9 / 18.7, <4,16,no> 38.5 / 20.2 (14 registers spilled at the 128-VGPR limit of a 16-wave workgroup),
+  // <4,8,no> 39.4 / 21.2, <4,12,yes> 39.9 / 19.5, <1,16,no> 36.8 / 21.9, <6,16,no> 43.3 / 23.1
+  switch (variant) {  // experiments: SV_THIN_VARIANT=10, 20
+    case 10: return launch_conv_thin_lds_t<4, 16, false>(p, stream);
+    case 20: return launch_conv_thin_lds_t<2, 16, true>(p, stream);
+    default: return launch_conv_thin_lds_t<2, 16, false>(p, stream);
+  }
 }
 
 static int launch_conv_thin(const ConvParams& p, hipStream_t stream) {
@@ -1344,7 +1368,7 @@ static int launch_conv_thin(const ConvParams& p, hipStream_t stream) {
   // sub-tiles per wave (shared weight registers) 27-28 / 48 us, three or six offsets in flight 26 / 51-54 us.
   static const int variant = getenv("SV_THIN_VARIANT") ? atoi(getenv("SV_THIN_VARIANT")) : -1;  // experiments only
   // default (round 4): the layer's weights resident in LDS, one 16-wave workgroup per CU (conv_thin_lds_kernel)
-  if (variant < 0 && p.K <= 27 && (((uintptr_t)p.W) & 15) == 0) return launch_conv_thin_lds(p, stream);
+  if ((variant < 0 || variant >= 10) && p.K <= 27 && (((uintptr_t)p.W) & 15) == 0) return launch_conv_thin_lds(p, stream, variant);
   const dim3 g1((unsigned)(p.Vpad / 64)), g2((unsigned)(p.Vpad / 64), 2);
   switch (variant) {
     case 1: hipLaunchKernelGGL((conv_thin_kernel<32, 32, 1, 4, 2>), g2, dim3(256), 0, stream, p); break;

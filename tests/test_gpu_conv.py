@@ -186,8 +186,10 @@ def test_relu_epilogue_propagates_nan_like_torch(gpu, oracle):
 
 
 def test_thin_wave_per_subtile_kernel_strided_and_batched(gpu, oracle):
-    """conv_thin_kernel<32, 32> (one wave per 16-row sub-tile, direct register gathers, lane-group transposes): a column
-    slice of a wider buffer as input AND as output, a two-frame batch, every epilogue option, and the 8-offset maps."""
+    """The thin 32 -> 32 kernels (one wave per 16-row sub-tile, direct register gathers, lane-group transposes;
+    conv_thin_lds_kernel: the layer's weights resident in LDS, sub-tiles pulled from a per-workgroup queue;
+    conv_thin_kernel: weights through L1, taken when the weight pointer is not 16-byte aligned): a column slice of a
+    wider buffer as input AND as output, a two-frame batch, every epilogue option, and the 8-offset maps."""
     from mrcc_amd import nn as svnn
     from mrcc_amd import profiling
 
@@ -196,7 +198,9 @@ def test_thin_wave_per_subtile_kernel_strided_and_batched(gpu, oracle):
     frame = oracle.Frame(oracle.voxelize(coords4)["coords"])
     V = st.F.shape[0]
     plan = cm.plan_k3(1)
-    assert profiling.conv_kernel_config(32, plan.Vpad, 32, 27) == "conv_thin_kernel<32, 32>"
+    import mrcc_amd
+
+    assert profiling.conv_kernel_config(32, plan.Vpad, 32, 27) == "conv_thin_lds_kernel<32, 32>"
     rng = np.random.default_rng(11)
     wide_in = rng.normal(size=(V, 80)).astype(np.float32)
     W = (rng.normal(size=(27, 32, 32)) * 0.1).astype(np.float32)
@@ -210,6 +214,14 @@ def test_thin_wave_per_subtile_kernel_strided_and_batched(gpu, oracle):
     want = oracle.conv(np.ascontiguousarray(wide_in[:, 16:48]), W, frame.k3(1), V, scale, shift, res, oracle.ACT_LEAKY, 0.05)
     assert np.array_equal(out_buf[:, 32:64].cpu().numpy(), want)
     assert (out_buf[:, :32] == 7.0).all() and (out_buf[:, 64:] == 7.0).all()  # neighbours of the slice untouched
+    assert mrcc_amd._lib.conv_last_instance()[0] == "conv_thin_lds_kernel<32, 32>"
+    # a weight tensor that starts 4 bytes off a 16-byte boundary cannot be staged with float4 copies: the round-3 kernel
+    # (weights through L1) takes the launch - same bits
+    w_off = torch.zeros(27 * 32 * 32 + 1, device=gpu)
+    w_off[1:] = t(W).reshape(-1)
+    out2 = svnn.conv_forward(x, w_off[1:].view(27, 32, 32), plan, V, t(scale), t(shift), t(res), 2, 0.05)
+    assert mrcc_amd._lib.conv_last_instance()[0] == "conv_thin_kernel<32, 32>"
+    assert np.array_equal(out2.cpu().numpy(), want)
     # bias-only epilogue (no scale), no residual, no activation
     got = svnn.conv_forward(x, t(W), plan, V, None, t(shift)).cpu().numpy()
     assert np.array_equal(got, oracle.conv(np.ascontiguousarray(wide_in[:, 16:48]), W, frame.k3(1), V, None, shift))

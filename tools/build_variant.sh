@@ -11,5 +11,5 @@ SRC=${SRC:-$C/sv_conv.hip}
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -I$C -Wno-unused-result -ffp-contract=off \
   -mllvm -amdgpu-mfma-vgpr-form=1 "$@" -c $SRC -o $ROOT/exp/sv_conv_$name.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/exp/libsvhip_$name.so $ROOT/exp/sv_conv_$name.o \
-  $C/sv_coords.o $C/sv_sort.o $C/sv_post.o $C/sv_dense.o $C/sv_points.o $C/sv_icp.o $C/sv_cluster.o
+  $C/sv_coords.o $C/sv_sort.o $C/sv_frame.o $C/sv_post.o $C/sv_dense.o $C/sv_points.o $C/sv_icp.o $C/sv_cluster.o
 echo built exp/libsvhip_$name.so

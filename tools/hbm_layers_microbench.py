@@ -52,10 +52,10 @@ import tempfile
 
 tmp = tempfile.mkdtemp()
 base = None
-for label, env in (("default", {}), ("conv0 VALU kernel", {"SV_CONV_FIRST_VALU": "1"}), ("thin variant 0 (one wave, 32 cols, D=4)", {"SV_THIN_VARIANT": "0"}),
-                   ("thin variant 1 (16 cols per wave, D=4)", {"SV_THIN_VARIANT": "1"}),
-                   ("thin variant 2 (16 cols, D=6)", {"SV_THIN_VARIANT": "2"}), ("thin variant 3 (16 cols, D=8)", {"SV_THIN_VARIANT": "3"}),
-                   ("thin variant 4 (32 cols, D=8)", {"SV_THIN_VARIANT": "4"})):
+for label, env in (("default", {}), ("conv0 VALU kernel", {"SV_CONV_FIRST_VALU": "1"}),
+                   ("thin variant 0 (round 3: weights through L1, one wave per sub-tile, D=4)", {"SV_THIN_VARIANT": "0"}),
+                   ("thin variant 10 (LDS weights, D=4, 16 waves)", {"SV_THIN_VARIANT": "10"}),
+                   ("thin variant 20 (LDS weights, D=2, 16 waves, next table prefetched)", {"SV_THIN_VARIANT": "20"})):
     if len(sys.argv) > 1 and label != "default" and env.get("SV_THIN_VARIANT") not in sys.argv[1:]:
         continue  # `python tools/hbm_layers_microbench.py 5 6`: the default and those thin-kernel variants only
     print(label, flush=True)
