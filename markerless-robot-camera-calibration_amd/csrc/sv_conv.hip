@@ -117,7 +117,11 @@ __device__ __forceinline__ auto buffer_load_floats(__amdgpu_buffer_rsrc_t rsrc, 
 constexpr int chunk_for(int tm, int waves_n) {
   if (waves_n == 1) return tm <= 64 ? 128 : 64;  // tall-narrow tiles (small levels): few, fat steps
   if (waves_n == 2) return tm <= 32 ? 128 : (tm <= 64 ? 64 : 32);
+#ifdef SV_EXP_KC16
+  return tm <= 16 ? 128 : (tm <= 32 ? 32 : 16);  // experiment: 16-channel steps on the 64-row tiles, 32 on the 32-row ones (fewer B / gather registers: five waves per SIMD)
+#else
   return tm <= 16 ? 128 : (tm <= 32 ? 64 : 32);
+#endif
 }
 
 // Workgroup = 4 waves.  Tile = TM_ output rows (mask-sorted plan order) x TN output channels.

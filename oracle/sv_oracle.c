@@ -109,23 +109,20 @@ int or_voxel_reduce(const float* feats, int C, const int32_t* order, const int32
   return 0;
 }
 
-/* ME.MinkowskiGlobalMaxPooling / GlobalAvgPooling over rows [bs[b], bs[b+1]) — same 4-way strided partial order as
- * the device kernel for AVG so that the sum is reproducible: partial w sums rows s+w, s+w+4, ...; then p0+p1+p2+p3. */
+/* ME.MinkowskiGlobalMaxPooling / GlobalAvgPooling over rows [bs[b], bs[b+1]) (model/robotnet.py:43, robotnet_encode.py:41).
+ * MAX is order-free.  AVG: a plain sequential float32 sum in row order divided by the row count - the oracle states the
+ * operation, not the device kernel's reduction tree; a float32 mean depends on the summation order in its last bits, so
+ * comparisons with the GPU's pooled values carry a tolerance (1e-4, the north_star's on pose floats; tests/test_gpu_model.py)
+ * and the order-free float64 check lives in tests/test_gpu_dense_grid.py. */
 int or_global_pool(const float* F, int64_t ld, int C, const int32_t* batch_start, int B, int mode, float* out) {
   for (int b = 0; b < B; ++b) {
     int s = batch_start[b], e = batch_start[b + 1];
     for (int c = 0; c < C; ++c) {
-      float part[4];
-      for (int w = 0; w < 4; ++w) {
-        float acc = mode == 0 ? -INFINITY : 0.0f;
-        for (int r = s + w; r < e; r += 4) {
-          float v = F[(int64_t)r * ld + c];
-          acc = mode == 0 ? fmaxf(acc, v) : acc + v;
-        }
-        part[w] = acc;
+      float a = mode == 0 ? -INFINITY : 0.0f;
+      for (int r = s; r < e; ++r) {
+        float v = F[(int64_t)r * ld + c];
+        a = mode == 0 ? fmaxf(a, v) : a + v;
       }
-      float a = part[0];
-      for (int w = 1; w < 4; ++w) a = mode == 0 ? fmaxf(a, part[w]) : a + part[w];
       if (mode == 1) a = e > s ? a / (float)(e - s) : 0.0f;
       if (mode == 0 && e <= s) a = 0.0f;
       out[(int64_t)b * C + c] = a;
