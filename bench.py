@@ -590,12 +590,18 @@ def other_configs_block(model, device, streams, checked):
         o2 = O.conv(o1, sd_["regression.2.linear.weight"].numpy().T[None], None, len(rows), None,
                     sd_["regression.2.linear.bias"].numpy())
         lg = logits.F.cpu().numpy()
+        gf5_seg = profiling.pass_gflop(lambda: model(x))
+        gf5_vote = profiling.pass_gflop(lambda: vote(x))
+        e2e = lambda gf, sec: {"gflop_per_frame": round(gf, 1), "tflops": round(gf / sec / 1e3, 2),  # noqa: E731
+                               "frac_of_f32_mfma_peak": round(gf / sec / 1e3 / PEAK_F32_MFMA_TFLOPS, 4)}
         out["cfg5"] = {
             "workload": "cfg5: 500k-pt cloud, 1 cm voxels, seg -> vote -> pose: voxelise + maps, RobotNetSegmentation and "
                         "RobotNetVote (both MinkUNet18D heads) on the frame, slice/argmax of both, one Kabsch solve",
             "value": round(1.0 / dt5_full, 3), "unit": "frames/s", "ms_per_frame": round(dt5_full * 1e3, 3), "frames_timed": 6,
+            "end_to_end": e2e(gf5_seg + gf5_vote, dt5_full),
             "seg_only": {"value": round(1.0 / dt5, 3), "unit": "frames/s", "ms_per_frame": round(dt5 * 1e3, 3), "frames_timed": n5,
-                         "what": "voxelise + maps + seg U-Net + slice/argmax (the headline pipeline at 3.5x the voxels)"},
+                         "what": "voxelise + maps + seg U-Net + slice/argmax (the headline pipeline at 3.5x the voxels)",
+                         "end_to_end": e2e(gf5_seg, dt5)},
             "active_voxels_per_frame": int(vox5 // n5),
             "parity": {"voxel_keys_equal": bool(np.array_equal(x.coordinate_map.keys.cpu().numpy().view(np.uint64), vox["keys"])),
                        "inverse_equal": bool(np.array_equal(field.inverse_mapping.cpu().numpy(), vox["inverse"])),
@@ -638,6 +644,8 @@ def other_configs_block(model, device, streams, checked):
             oracle_labels = bool(np.array_equal(lab[:POINTS].cpu().numpy(), checked["ref"]["label"]))
         Ro, to = O.get_rigid_transform_3D(kp_ref[0], kp_tgt[0])
         V3 = xs.F.shape[0]
+        gf3_seg = profiling.pass_gflop(lambda: model(xs))
+        gf3_vote = profiling.pass_gflop(lambda: vote(xs))
         del xs, o, lab, x1, o1_, f1
         t0 = time.perf_counter()
         n3 = 2
@@ -655,8 +663,10 @@ def other_configs_block(model, device, streams, checked):
             "workload": f"cfg3: {B} synthetic 200k-pt frames in ONE sparse tensor (batch column): seg + keypoint-vote (two "
                         f"MinkUNet18D heads on the batch) + slice/argmax of both + {B} Kabsch problems",
             "value": round(B / dt3_full, 3), "unit": "frames/s", "ms_per_batch": round(dt3_full * 1e3, 2), "batches_timed": 1,
+            "end_to_end": dict(e2e(gf3_seg + gf3_vote, dt3_full), gflop_per_frame=round((gf3_seg + gf3_vote) / B, 1)),
             "seg_only": {"value": round(B / dt3, 3), "unit": "frames/s", "ms_per_batch": round(dt3 * 1e3, 2), "batches_timed": n3,
-                         "what": f"seg U-Net forward + slice/argmax + {B} Kabsch problems"},
+                         "what": f"seg U-Net forward + slice/argmax + {B} Kabsch problems",
+                         "end_to_end": dict(e2e(gf3_seg, dt3), gflop_per_frame=round(gf3_seg / B, 1))},
             "active_voxels": int(V3),
             "parity": {"frame0_equals_single_frame_run_bit_exact": same, "frame0_labels_equal_oracle": oracle_labels,
                        "all_wide_layer_launches_on_fast_instances": bool(wide and all(e[1]["fast"] == 1 for e in wide)),

@@ -153,3 +153,16 @@ class KernelTimer:
             d["flops"] += 2.0 * P * Cin * Cout
             d["bytes"] += P * (4.0 * Cin + 8) + 4.0 * V_out * Cout + 4.0 * K * Cin * Cout
         return out
+
+
+def pass_gflop(fn):
+    """Algorithmic GFLOP (2 P Cin Cout per conv / linear layer, P = kernel-map pairs or dense rows) of the
+    sv_conv_fwd launches fn() makes - one forward pass's worth, counted by timing it once under a private KernelTimer."""
+    global TIMER
+    saved, TIMER = TIMER, KernelTimer()
+    try:
+        fn()
+        torch.cuda.synchronize()
+        return sum(d["flops"] for d in TIMER.summarize().values()) / 1e9
+    finally:
+        TIMER = saved

@@ -20,6 +20,7 @@ ap.add_argument("--cout", type=int, default=384)
 ap.add_argument("--level", type=int, default=0)
 ap.add_argument("--iters", type=int, default=200)  # long enough for the clocks to settle
 ap.add_argument("--points", type=int, default=200000)
+ap.add_argument("--scale", type=float, default=50.0, help="voxels per metre (50 = 2 cm: Cfg-2; 100 with --points 500000 = Cfg-5)")
 ap.add_argument("--kind", default="k3")
 ap.add_argument("--cube", type=int, default=0, help="solid cube of this edge length (voxels) instead of the room cloud")
 ap.add_argument("--split", default="0", help="run the 3x3x3 layer as passes over offset ranges: 14 -> [0,14) [14,27); 9,18 -> three")
@@ -33,7 +34,7 @@ if args.cube:
     rgb = np.zeros((len(xyz), 3), np.float32)
 else:
     pts, rgb, _ = mrcc_amd.synth.gen_room(args.points, 2.4, 0)
-    coords4 = np.concatenate([np.zeros((len(pts), 1), np.float32), pts * np.float32(50)], axis=1)
+    coords4 = np.concatenate([np.zeros((len(pts), 1), np.float32), pts * np.float32(args.scale)], axis=1)
 x = ME.TensorField(torch.from_numpy(rgb), torch.from_numpy(coords4), device=dev).sparse()
 cm = x.coordinate_manager
 ts = 2 ** args.level
