@@ -382,7 +382,9 @@ def hbm_bound_layers(model, device, iters=60):
             _log(f"hbm_bound_layers: graph capture unavailable ({type(exc).__name__}); eager series only")
         return eager, graph_us
 
-    with torch.no_grad():
+    # every layer here runs ALONE on the GPU: the dispatch of a GPU that holds one frame (sv_conv_set_dispatch(1.0), what the
+    # per-frame InferenceEngine.predict path uses) - for the thin 32 -> 32 layers that is the LDS-weights kernel
+    with torch.no_grad(), mrcc_amd._lib.conv_dispatch(1.0):
         tiny = torch.zeros(1, 32, device=device)
         tiny_out = torch.empty_like(tiny)
         w1 = torch.zeros(1, 32, 32, device=device)

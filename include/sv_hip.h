@@ -230,7 +230,9 @@ const char* sv_conv_last_instance(void);
  * time; inside a multi-stream frame pipeline taller tiles win earlier (their launch tails are filled by the neighbour
  * frames' kernels), so the library default scales every "chosen from N workgroups" threshold by 0.3.  A caller that runs
  * ONE frame at a time (the reference's consumer: InferenceEngine.predict per frame, app/main.py:432-456) sets
- * want_scale = 1.  tail_fraction = share of the plan tiles that chip-filling launches run as half-height tiles.
+ * want_scale = 1 - which also selects, for the thin 32 -> 32 layers, the kernel that keeps the layer's weights in LDS (one
+ * 16-wave workgroup per CU: it needs whole CUs, which only a GPU that holds one frame has free).
+ * tail_fraction = share of the plan tiles that chip-filling launches run as half-height tiles.
  * A negative value restores the library default (environment SV_CONV_WANT_SCALE / SV_CONV_TAIL).  Results never depend on
  * the instance (one fma chain per output element in every one of them). */
 int sv_conv_set_dispatch(double want_scale, double tail_fraction);

@@ -1371,8 +1371,15 @@ static int launch_conv_thin(const ConvParams& p, hipStream_t stream) {
   // on the LDS-staged fused-offset tile, 49 against 84 us at 88k voxels (2.65 TB/s on algorithmic gather-bytes).  Two
   // sub-tiles per wave (shared weight registers) 27-28 / 48 us, three or six offsets in flight 26 / 51-54 us.
   static const int variant = getenv("SV_THIN_VARIANT") ? atoi(getenv("SV_THIN_VARIANT")) : -1;  // experiments only
-  // default (round 4): the layer's weights resident in LDS, one 16-wave workgroup per CU (conv_thin_lds_kernel)
-  if ((variant < 0 || variant >= 10) && p.K <= 27 && (((uintptr_t)p.W) & 15) == 0) return launch_conv_thin_lds(p, stream, variant);
+  // Round 4: the layer's weights resident in LDS, one 16-wave workgroup per CU (conv_thin_lds_kernel) - for a GPU that holds
+  // ONE frame (the caller said so: sv_conv_set_dispatch(want_scale >= 1), the per-frame InferenceEngine.predict path and
+  // every measurement of a layer alone).  Its workgroup needs a whole CU - 145 KB of LDS, sixteen wave slots at 126 VGPRs -
+  // and beside the convolutions of other frames a CU only drains completely when a launch ends: inside the three-stream
+  // pipeline its launches wait 0.2-3.6 ms for CUs (profiles/r04_bench_kernel_by_grid.txt, r04_cfg5_kernel_by_grid.txt) and
+  // predict_stream loses 4 % (profiles/r04_ab_thin_in_pipeline.txt); there the four-wave workgroups of conv_thin_kernel,
+  // which fit the slot any finishing convolution workgroup frees, stay the choice.  Same bits either way.
+  const bool alone = g_want_scale_override >= 1.0;
+  if ((variant < 0 ? alone : variant >= 10) && p.K <= 27 && (((uintptr_t)p.W) & 15) == 0) return launch_conv_thin_lds(p, stream, variant);
   const dim3 g1((unsigned)(p.Vpad / 64)), g2((unsigned)(p.Vpad / 64), 2);
   switch (variant) {
     case 1: hipLaunchKernelGGL((conv_thin_kernel<32, 32, 1, 4, 2>), g2, dim3(256), 0, stream, p); break;

@@ -49,9 +49,9 @@ def conv_kernel_config(Cout, Vpad, Cin=None, K=1):
     if K > 1 and Cin == 3 and Cout == 32:
         return "conv_first_mfma_kernel<3, 32>"  # (SV_CONV_FIRST_VALU: the thread-per-voxel VALU kernel it replaced)
     if K > 1 and Cin == 32 and Cout == 32:
-        if os.environ.get("SV_THIN_VARIANT", "-1") in ("0", "1", "2", "3", "4"):
-            return "conv_thin_kernel<32, 32>"  # round 3: wave-per-sub-tile direct gather, weights through L1
-        return "conv_thin_lds_kernel<32, 32>"  # the layer's weights resident in LDS, one 16-wave workgroup per CU
+        # conv_thin_lds_kernel (weights resident in LDS, one 16-wave workgroup per CU) under sv_conv_set_dispatch(>= 1): one
+        # frame alone on the GPU; the recorded name is the library's (sv_conv_last_instance), this one only gates timing
+        return "conv_thin_kernel<32, 32>"
     fused = None
     if K > 1 and Cin is not None:
         if Cin == 3 and 16 < Cout <= 32:

@@ -200,7 +200,7 @@ def test_thin_wave_per_subtile_kernel_strided_and_batched(gpu, oracle):
     plan = cm.plan_k3(1)
     import mrcc_amd
 
-    assert profiling.conv_kernel_config(32, plan.Vpad, 32, 27) == "conv_thin_lds_kernel<32, 32>"
+    assert profiling.conv_kernel_config(32, plan.Vpad, 32, 27) == "conv_thin_kernel<32, 32>"
     rng = np.random.default_rng(11)
     wide_in = rng.normal(size=(V, 80)).astype(np.float32)
     W = (rng.normal(size=(27, 32, 32)) * 0.1).astype(np.float32)
@@ -210,18 +210,28 @@ def test_thin_wave_per_subtile_kernel_strided_and_batched(gpu, oracle):
     t = lambda a: torch.from_numpy(a).to(gpu)
     x = t(wide_in)[:, 16:48]  # row stride 80 floats, 16-byte aligned start
     out_buf = torch.full((V, 96), 7.0, device=gpu)
-    svnn.conv_forward(x, t(W), plan, V, t(scale), t(shift), t(res), 2, 0.05, out=out_buf[:, 32:64])
     want = oracle.conv(np.ascontiguousarray(wide_in[:, 16:48]), W, frame.k3(1), V, scale, shift, res, oracle.ACT_LEAKY, 0.05)
+    # default dispatch (frames overlapped in a multi-stream pipeline): four-wave workgroups, weights through L1
+    svnn.conv_forward(x, t(W), plan, V, t(scale), t(shift), t(res), 2, 0.05, out=out_buf[:, 32:64])
+    assert mrcc_amd._lib.conv_last_instance()[0] == "conv_thin_kernel<32, 32>"
     assert np.array_equal(out_buf[:, 32:64].cpu().numpy(), want)
     assert (out_buf[:, :32] == 7.0).all() and (out_buf[:, 64:] == 7.0).all()  # neighbours of the slice untouched
-    assert mrcc_amd._lib.conv_last_instance()[0] == "conv_thin_lds_kernel<32, 32>"
-    # a weight tensor that starts 4 bytes off a 16-byte boundary cannot be staged with float4 copies: the round-3 kernel
-    # (weights through L1) takes the launch - same bits
-    w_off = torch.zeros(27 * 32 * 32 + 1, device=gpu)
-    w_off[1:] = t(W).reshape(-1)
-    out2 = svnn.conv_forward(x, w_off[1:].view(27, 32, 32), plan, V, t(scale), t(shift), t(res), 2, 0.05)
-    assert mrcc_amd._lib.conv_last_instance()[0] == "conv_thin_kernel<32, 32>"
-    assert np.array_equal(out2.cpu().numpy(), want)
+    # the dispatch of a GPU that holds ONE frame (sv_conv_set_dispatch(1.0): the per-frame InferenceEngine.predict path):
+    # the layer's weights resident in LDS, one 16-wave workgroup per CU, sub-tiles pulled from a per-workgroup queue
+    with mrcc_amd._lib.conv_dispatch(1.0):
+        out_buf.fill_(7.0)
+        svnn.conv_forward(x, t(W), plan, V, t(scale), t(shift), t(res), 2, 0.05, out=out_buf[:, 32:64])
+        assert mrcc_amd._lib.conv_last_instance()[0] == "conv_thin_lds_kernel<32, 32>"
+        assert np.array_equal(out_buf[:, 32:64].cpu().numpy(), want)
+        assert (out_buf[:, :32] == 7.0).all() and (out_buf[:, 64:] == 7.0).all()
+        # a weight tensor that starts 4 bytes off a 16-byte boundary cannot be staged with float4 copies: the other kernel
+        # takes the launch - same bits
+        w_off = torch.zeros(27 * 32 * 32 + 1, device=gpu)
+        w_off[1:] = t(W).reshape(-1)
+        out2 = svnn.conv_forward(x, w_off[1:].view(27, 32, 32), plan, V, t(scale), t(shift), t(res), 2, 0.05)
+        assert mrcc_amd._lib.conv_last_instance()[0] == "conv_thin_kernel<32, 32>"
+        assert np.array_equal(out2.cpu().numpy(), want)
+
     # bias-only epilogue (no scale), no residual, no activation
     got = svnn.conv_forward(x, t(W), plan, V, None, t(shift)).cpu().numpy()
     assert np.array_equal(got, oracle.conv(np.ascontiguousarray(wide_in[:, 16:48]), W, frame.k3(1), V, None, shift))
@@ -234,6 +244,12 @@ def test_thin_wave_per_subtile_kernel_strided_and_batched(gpu, oracle):
     xc = rng.normal(size=(Vc, 32)).astype(np.float32)
     got = svnn.conv_forward(t(xc), t(W8), cm.plan_up(2), V).cpu().numpy()
     assert np.array_equal(got, oracle.conv(xc, W8, frame.kup(2), V))
+    with mrcc_amd._lib.conv_dispatch(1.0):  # the 8-offset maps on the LDS-weights kernel
+        got = svnn.conv_forward(t(xf), t(W8), cm.plan_down(1), Vc, act=1).cpu().numpy()
+        assert mrcc_amd._lib.conv_last_instance()[0] == "conv_thin_lds_kernel<32, 32>"
+        assert np.array_equal(got, oracle.conv(xf, W8, frame.kdown(1), Vc, act=oracle.ACT_RELU))
+        got = svnn.conv_forward(t(xc), t(W8), cm.plan_up(2), V).cpu().numpy()
+        assert np.array_equal(got, oracle.conv(xc, W8, frame.kup(2), V))
 
 
 @pytest.mark.parametrize("cin,cout", [(64, 64), (96, 384)])

@@ -27,6 +27,10 @@ ap.add_argument("--split", default="0", help="run the 3x3x3 layer as passes over
 args = ap.parse_args()
 
 dev = torch.device("cuda:0")
+if args.cin == 32 and args.cout == 32:  # the thin layers: one layer alone on the GPU = the one-frame dispatch (LDS-weights kernel)
+    import ctypes
+
+    mrcc_amd._lib.call("sv_conv_set_dispatch", ctypes.c_double(1.0), ctypes.c_double(-1.0))
 if args.cube:
     g = np.arange(args.cube, dtype=np.float32) + 0.5
     xyz = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3)

@@ -18,6 +18,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     from mrcc_amd import nn as svnn
 
     dev = torch.device("cuda:0")
+    mrcc_amd._lib.call("sv_conv_set_dispatch", __import__("ctypes").c_double(1.0), __import__("ctypes").c_double(-1.0))  # one layer alone
     pts, rgb, _ = mrcc_amd.synth.gen_room(200_000, 2.4, 0)
     coords4 = np.concatenate([np.zeros((len(pts), 1), np.float32), pts * np.float32(50)], axis=1)
     x = ME.TensorField(torch.from_numpy(rgb), torch.from_numpy(coords4), device=dev).sparse()

@@ -7,6 +7,7 @@ import mrcc_amd
 from mrcc_amd import MinkowskiEngine as ME
 from mrcc_amd import nn as svnn
 dev = torch.device("cuda:0")
+mrcc_amd._lib.call("sv_conv_set_dispatch", __import__("ctypes").c_double(1.0), __import__("ctypes").c_double(-1.0))
 pts, rgb, _ = mrcc_amd.synth.gen_room(200_000, 2.4, 0)
 c4 = np.concatenate([np.zeros((len(pts), 1), np.float32), pts * np.float32(50)], axis=1)
 x = ME.TensorField(torch.from_numpy(rgb), torch.from_numpy(c4), device=dev).sparse()
