@@ -201,7 +201,12 @@ class InferenceEngine:
         runner = self._crop_runner()
 
         def nets(x, field, seg_start):
-            return self._rotation_model(x), self._kp_select(x, field, seg_start, G, conf_th)
+            # the two networks only share their input: the rotation network runs on the runner's side stream while the
+            # key-point network is enqueued and runs on the main one
+            rot = runner.fork(lambda: self._rotation_model(x))
+            kp = self._kp_select(x, field, seg_start, G, conf_th)
+            runner.join()
+            return rot, kp
 
         rot, kp = runner.run(pts, crops_rgb, cfg.INFERENCE.ROTATION.scale, nets, one_frame=one_frame)
         (host,), ev, keep = runner.download([rot])

@@ -322,6 +322,8 @@ class CropBatchRunner:
         # high priority, as the prep stream: the crops' few hundred short workgroups must not queue behind the thousands of
         # convolution workgroups of the segmentation frames in flight (the host waits for this stream's size read-backs)
         self.stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("MRCC_PREP_PRIORITY", "-1")))
+        # two networks that read the same voxelised batch are independent of each other: the second one runs here
+        self.side = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("MRCC_PREP_PRIORITY", "-1")))
         self.up = PinnedRing()
         self.down = PinnedRing(slots=12)
 
@@ -366,6 +368,28 @@ class CropBatchRunner:
             cm.build_plans(self.levels, up=not encoder_only, split=not encoder_only)
             with (_lib.conv_dispatch(1.0) if one_frame else contextlib.nullcontext()):
                 return fn(x, field, seg_start)
+
+    def fork(self, fn):
+        """fn() on the side stream, behind everything enqueued on the main stream so far; the main stream waits for it at
+        join().  Launch-bound networks on a few thousand voxels leave most of the GPU idle: two of them side by side take
+        about as long as the longer one.  Returns fn's result (tensors: valid on the main stream after join)."""
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        self.side.wait_event(ev)
+        with torch.cuda.stream(self.side):
+            out = fn()
+            self._joined = torch.cuda.Event()
+            self._joined.record(self.side)
+        for t in (out if isinstance(out, (tuple, list)) else (out,)):
+            if torch.is_tensor(t):
+                t.record_stream(self.stream)
+        return out
+
+    def join(self):
+        ev = getattr(self, "_joined", None)
+        if ev is not None:
+            self.stream.wait_event(ev)
+            self._joined = None
 
     def download(self, tensors):
         """device tensors -> (list of pinned host views, event): one asynchronous D2H each on the runner's stream"""

@@ -271,3 +271,29 @@ def test_three_nn_interpolation_matches_reference_formulation(gpu, B, N, S, C):
     want = torch.sum(P2.index_points(pts2, idx) * w.view(B, N, 3, 1), dim=2)
     assert got.shape == want.shape == (B, N, C)
     assert (got - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+
+
+def test_topk_indices_selection_equals_a_stable_descending_sort(gpu):
+    """sv_topk_indices (utils/output.py:45-64 get_pred_center: `out[:, 1].sort(descending=True)[1][:8]` as a two-stage
+    selection): the k largest entries of a strided column, largest first, ties to the lower row - against a stable descending
+    sort on the host, for sizes around the 8 192-value chunk of the first stage, many ties, negative values, infinities, fewer
+    rows than k, and k up to 64."""
+    from mrcc_amd.utils.output import topk_indices
+
+    rng = np.random.default_rng(7)
+    for n, k, kind in ((200_000, 8, "normal"), (8192, 8, "ties"), (8193, 16, "ties"), (50_000, 64, "normal"), (5, 8, "normal"),
+                       (1, 8, "normal"), (20_000, 8, "neg"), (3000, 8, "inf")):
+        if kind == "ties":
+            col = rng.integers(0, 5, size=n).astype(np.float32)
+        elif kind == "neg":
+            col = -np.abs(rng.normal(size=n)).astype(np.float32) - 1.0
+        else:
+            col = rng.normal(size=n).astype(np.float32)
+        if kind == "inf":
+            col[[17, 900]] = np.inf
+            col[[3, 2999]] = -np.inf
+        votes = np.zeros((n, 4), np.float32)
+        votes[:, 1] = col
+        got = topk_indices(torch.from_numpy(votes).to(gpu)[:, 1], k).cpu().numpy()
+        want = np.argsort(-col.astype(np.float64), kind="stable")[:k]  # descending, ties in ascending row order
+        assert got.shape == want.shape and np.array_equal(got, want), (n, k, kind)

@@ -331,6 +331,42 @@ def _keyed_engine(seed=3):
     return eng
 
 
+def test_keyed_scene_labels_are_the_oracle_s_and_the_ground_truth(gpu, oracle):
+    """synth.wire_color_keyed_labels does not bypass the network: the oracle, given the wired weights, runs the whole
+    U-Net and predicts the same labels as the GPU path (bit-exact logits), and on a colour-keyed scene those labels are the
+    ground truth except in the few voxels that mix end-effector / arm points with background ones."""
+    import mrcc_amd
+    from mrcc_amd import MinkowskiEngine as ME
+    from mrcc_amd.utils import preprocess
+    from mrcc_amd.utils.config import Config
+
+    Config.reset()
+    Config().update({"INFERENCE": {"SEGMENTATION": {"scale": 50}}})
+    try:
+        eng = _keyed_engine(seed=5)
+        sc = mrcc_amd.synth.gen_scene(3, n_bg=7000, n_arm=900, n_ee=1500, keyed_colors=True)
+        pts, rgb = sc["points"], preprocess.normalize_colors(sc["rgb"])
+        got = eng.predict_segmentation(pts, rgb)
+        sd = {k: v.cpu() for k, v in eng._segmentation_model.state_dict().items()}
+        ref = oracle.predict_segmentation(sd, pts, rgb, 50)
+        with torch.no_grad():
+            field = eng._field(pts, rgb, 50)
+            logits = eng._segmentation_model(field.sparse()).F.cpu().numpy()
+        assert np.array_equal(logits, ref["logits"])  # full network, wired and random weights alike: bit-exact
+        want = ref["label"].copy()
+        ee = np.where(want == 2)[0]
+        want[ee] = 1
+        want[ee[eng.cluster_util.get_largest_cluster(pts[ee])]] = 2
+        assert np.array_equal(got, want)
+        gt = sc["segmentation"]
+        assert (got == gt).mean() > 0.97 and ((got == 2) & (gt == 2)).sum() > 0.95 * (gt == 2).sum()
+        # and the hidden layers are not idle: apart from the two wired channels the logits' inputs are random features
+        h = eng._segmentation_model.forward_except_final(eng._field(pts, rgb, 50).sparse()).F
+        assert (h[:, 2:].abs().mean() > 1e-3).item()
+    finally:
+        Config.reset()
+
+
 def _same_result(o, r):
     assert np.array_equal(o.segmentation, r.segmentation)
     for name in ("ee_pose", "key_points_pose", "base_pose", "key_points_base_pose"):
