@@ -176,7 +176,10 @@ class InferenceEngine:
 
         r = self.__dict__.get("_crops")
         if r is None:
-            r = self._crops = CropBatchRunner(self.device, levels=4)
+            # pyramid depth of the deeper of the two pose networks (MinkUNet: 4 stride-2 steps, AliveUNet: 7); a network with
+            # fewer levels simply leaves the deeper maps unused
+            levels = max(getattr(self._rotation_model, "N_LEVELS", 4), getattr(self._key_points_model, "N_LEVELS", 4))
+            r = self._crops = CropBatchRunner(self.device, levels=levels)
         return r
 
     def _pose_nets_share_voxels(self):
