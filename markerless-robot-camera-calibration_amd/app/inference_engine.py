@@ -25,10 +25,10 @@ from ..model.pointnet2 import PointNet2SSG
 from ..model.robotnet import make_robotnet, make_robotnet_encode
 from ..model.robotnet_segmentation import _classification_head, make_robotnet_segmentation
 from ..utils import calibration as calib_util
-from ..utils import config, metrics, preprocess
+from ..utils import config, preprocess
 from ..utils import output as out_utils
 from ..utils.data import get_farthest_point_sample_idx
-from ..utils.transformation import (get_base2cam_matrix, get_base2cam_pose, get_q_from_matrix,
+from ..utils.transformation import (get_base2cam_matrix, get_q_from_matrix,
                                     get_quaternion_rotation_matrix, get_rigid_transform_3D,
                                     get_rigid_transform_3D_batched, transform_pose2pose)
 from .dto import CalibrationResultDTO, PointCloudDTO, ResultDTO, TestResultDTO
