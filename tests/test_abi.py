@@ -42,6 +42,23 @@ def test_argument_validation_without_gpu():
     assert rc == -1 and b"too large" in lib.sv_last_error()
     assert lib.sv_voxelize_workspace_bytes(200000) > 200000 * 8 * 2
     assert lib.sv_plan_workspace_bytes(88000) > 88000 * 4 * 3
+    # frame composites (ABI v4): argument checks and arena sizes are host code
+    rc = lib.sv_frame_maps(None, 0, 0, 4, None, 0, None, 0, None, None, None)
+    assert rc == -1 and b"at least one point" in lib.sv_last_error()
+    rc = lib.sv_frame_maps(None, 0, 100, 99, None, 0, None, 0, None, None, None)
+    assert rc == -1 and b"levels out of range" in lib.sv_last_error()
+    n = 200_000
+    assert lib.sv_frame_maps_arena_bytes(n, 4) >= n * (8 + 16 + 8 + 4 + 4) + 4 * n * (8 + 16 + 4 + 4)  # worst case V_l <= N
+    assert lib.sv_frame_maps_scratch_bytes(n) >= lib.sv_voxelize_workspace_bytes(n)
+    V = (ctypes.c_int64 * 5)(88113, 26552, 6849, 1732, 418)
+    cuts = (ctypes.c_int32 * 20)(9, 18, 0, 0, 9, 18, 0, 0)
+    k3 = lib.sv_frame_plans_arena_bytes(V, 4, 1, None)
+    every = lib.sv_frame_plans_arena_bytes(V, 4, 1 | 2 | 4 | 8, cuts)
+    assert k3 >= 88113 * 27 * 4 * 2 and every > k3 + 88113 * 27 * 4  # 27-offset map + plan; + down / up / three range plans
+    assert lib.sv_frame_plans_scratch_bytes(V, 4) == lib.sv_plan_workspace_bytes(88113)
+    rc = lib.sv_conv_set_dispatch(ctypes.c_double(1.0), ctypes.c_double(1.5))
+    assert rc == -1 and b"tail_fraction" in lib.sv_last_error()
+    assert lib.sv_conv_set_dispatch(ctypes.c_double(-1.0), ctypes.c_double(-1.0)) == 0
 
 
 def test_product_path_refuses_cpu_tensors():

@@ -194,3 +194,28 @@ def test_split_rules_parse_and_apply():
         svnn.SPLIT_RULES = old
     # the default: three passes on maps of at least 20 000 voxels (tools/ab_split.sh)
     assert svnn._parse_split_rules("20000:9,18") == [(20000, (9, 18))]
+
+
+def test_wired_colour_key_labels_on_the_oracle(oracle):
+    """synth.wire_color_keyed_labels + synth.gen_scene(keyed_colors=True), without a GPU: the ORACLE runs the whole
+    MinkUNet18D head with the wired weights (every other weight random) on a small colour-keyed scene and predicts the
+    ground-truth labels except in the few voxels that mix classes - the labelled frames the engine tests and the bench's
+    `predict_full` rely on are labelled by construction, by the network itself."""
+    import mrcc_amd
+    from mrcc_amd.model.robotnet_segmentation import RobotNetSegmentation
+    from mrcc_amd.utils import preprocess
+
+    torch.manual_seed(9)
+    model = mrcc_amd.synth.wire_color_keyed_labels(RobotNetSegmentation(in_channels=3, num_classes=3))
+    sc = mrcc_amd.synth.gen_scene(2, n_bg=2500, n_arm=400, n_ee=700, room=1.6, keyed_colors=True)
+    rgb = preprocess.normalize_colors(sc["rgb"])
+    assert rgb.min() >= -0.5 and rgb.max() <= 0.5
+    ref = oracle.predict_segmentation({k: v for k, v in model.state_dict().items()}, sc["points"], rgb, 50)
+    gt = sc["segmentation"]
+    assert (ref["label"] == gt).mean() > 0.97
+    assert ((ref["label"] == 2) & (gt == 2)).sum() > 0.95 * (gt == 2).sum() and ((ref["label"] == 1) & (gt == 1)).sum() > 0.9 * (gt == 1).sum()
+    # an unkeyed scene under the same weights has no end effector: nothing is bright red
+    sc2 = mrcc_amd.synth.gen_scene(2, n_bg=2500, n_arm=400, n_ee=700, room=1.6)
+    rgb2 = np.clip(preprocess.normalize_colors(sc2["rgb"]), -0.5, 0.05).astype(np.float32)
+    ref2 = oracle.predict_segmentation({k: v for k, v in model.state_dict().items()}, sc2["points"], rgb2, 50)
+    assert (ref2["label"] == 0).all()
