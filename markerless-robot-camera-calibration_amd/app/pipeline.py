@@ -17,6 +17,24 @@ import torch
 from .. import MinkowskiEngine as ME
 
 
+_STREAMS = {}
+
+
+def shared_stream(device, role, index=0, priority=0):
+    """One HIP stream per (device, role, index, priority) for the whole process.  HIP multiplexes streams onto a few hardware
+    queues (GPU_MAX_HW_QUEUES: 8 here); every pipeline object used to create its own prep / compute / crop streams, and once
+    a process had made more streams than queues, the compute streams of a NEW pipeline could share a queue - its frames then
+    ran one after the other (engine stream 70.2 -> 62.6 frames/s for the third engine of a process, bench.py's engine block
+    behind the other blocks).  Pipelines that are not used at the same time can share streams: stream order only adds
+    dependencies.  Roles: "prep", "compute" (index = position in the rotation), "crop", "crop_side"."""
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(), role, index, priority)
+    st = _STREAMS.get(key)
+    if st is None:
+        st = _STREAMS[key] = torch.cuda.Stream(device=dev, priority=priority)
+    return st
+
+
 class PreparedFrame:
     __slots__ = ("field", "x", "ready", "done", "tag", "stream", "result")
 
@@ -56,10 +74,10 @@ class FramePipeline:
         # the prep stream's ~150 small kernels per frame must not queue behind thousands of conv workgroups: the host
         # blocks on their size read-backs, and a late prepare() starves a compute stream (high priority = -1)
         prio = int(os.environ.get("MRCC_PREP_PRIORITY", "-1"))
-        self.prep_stream = torch.cuda.Stream(device=self.device, priority=prio)
+        self.prep_stream = shared_stream(self.device, "prep", 0, prio)
         # compute_streams > 1: consecutive frames run on alternating streams, so the small-pyramid-level and thin-layer
         # kernels of one frame (which cannot fill 256 CUs) overlap the big convolutions of its neighbour
-        self.compute_streams = [torch.cuda.Stream(device=self.device) for _ in range(compute_streams)] \
+        self.compute_streams = [shared_stream(self.device, "compute", i) for i in range(compute_streams)] \
             if compute_streams > 1 else []
         self._next_stream = 0
         # The stride-1 decoder stages (level 0: 63 % of a frame's flops, chip-filling launches) of consecutive frames take
@@ -321,9 +339,9 @@ class CropBatchRunner:
         self.levels = levels
         # high priority, as the prep stream: the crops' few hundred short workgroups must not queue behind the thousands of
         # convolution workgroups of the segmentation frames in flight (the host waits for this stream's size read-backs)
-        self.stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("MRCC_PREP_PRIORITY", "-1")))
+        self.stream = shared_stream(self.device, "crop", 0, int(os.environ.get("MRCC_PREP_PRIORITY", "-1")))
         # two networks that read the same voxelised batch are independent of each other: the second one runs here
-        self.side = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("MRCC_PREP_PRIORITY", "-1")))
+        self.side = shared_stream(self.device, "crop_side", 0, int(os.environ.get("MRCC_PREP_PRIORITY", "-1")))
         self.up = PinnedRing()
         self.down = PinnedRing(slots=12)
 
