@@ -326,9 +326,17 @@ __device__ __forceinline__ void conv_tile_body(const ConvParams& p, const int bi
   for (int s = 0; s < MR; ++s)
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[s][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // timing-only ablations (results WRONG; tools/build_variant.sh <name> -DSV_ABL=<bits>): 1 = no weight reloads in the
+  // loop, 2 = no gathers / LDS stores in the loop, 4 = no per-step barrier, 8 = A operands from a register, not LDS,
+  // 16 = no epilogue (one guarded store keeps the accumulators alive), 32 = no global reads in the prologue (table computed,
+  // no acc_init) - 16 + 32 bound what hiding a tile's fixed costs behind its neighbours' steps could gain (round 4: 2.6 %)
+#ifndef SV_ABL
+#define SV_ABL 0
+#endif
+  constexpr int ABL = SV_ABL;
 
   // ---- continue an earlier pass's chains: C operands from acc_init, addressed through `perm` like the epilogue's rows
-  if (p.acc_init) {
+  if (p.acc_init && !(ABL & 32)) {
     if constexpr (FAST) {
       const __amdgpu_buffer_rsrc_t rsrc_acc = __builtin_amdgcn_make_buffer_rsrc((void*)p.acc_init, 0, (int)p.acc_bytes, 0x00020000);
       int o_acc[MR][4];
@@ -372,7 +380,9 @@ __device__ __forceinline__ void conv_tile_body(const ConvParams& p, const int bi
       const int k = e / TM_, r = e % TM_;
       n_st[it] = -1;
       if (e < K * TM_) {
-        if (p.nbr_s)
+        if (ABL & 32)
+          n_st[it] = (int)((row0 + r + 97 * k) % p.V_out);
+        else if (p.nbr_s)
           n_st[it] = p.nbr_s[(int64_t)k * p.Vpad + row0 + r];
         else
           n_st[it] = (row0 + r < p.V_out) ? (int)(row0 + r) : -1;
@@ -451,12 +461,6 @@ __device__ __forceinline__ void conv_tile_body(const ConvParams& p, const int bi
 #define SV_GATHER_DEPTH 1
 #endif
   constexpr int GDEPTH = SV_GATHER_DEPTH;
-  // timing-only ablations (results WRONG; tools/build_variant.sh <name> -DSV_ABL=<bits>): 1 = no weight reloads in the
-  // loop, 2 = no gathers / LDS stores in the loop, 4 = no per-step barrier, 8 = A operands from a register, not LDS
-#ifndef SV_ABL
-#define SV_ABL 0
-#endif
-  constexpr int ABL = SV_ABL;
   float4 ra0[A_F4], ra1[A_F4];  // ra1 is dead (optimised away) at GDEPTH 1
   const int a_cc = (tid % Cfg::F4_PER_ROW) * 4;
   const int a_r = tid / Cfg::F4_PER_ROW;
@@ -734,7 +738,14 @@ __device__ __forceinline__ void conv_tile_body(const ConvParams& p, const int bi
     sc[n] = (p.scale && ok) ? p.scale[col0 + n] : 1.0f;
     sh[n] = (p.shift && ok) ? p.shift[col0 + n] : 0.0f;
   }
-  if constexpr (FAST) {
+  if constexpr (FAST && (ABL & 16) != 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int s = 0; s < MR; ++s)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) t += acc[s][n][0] + acc[s][n][1] + acc[s][n][2] + acc[s][n][3];
+    if (t == 12345.678f) p.out[0] = t;
+  } else if constexpr (FAST) {
     epilogue_buffered<MR, NT>(p, acc, row0 + wm * MR * 16, lq, col0);
   } else
 #pragma unroll
