@@ -95,6 +95,41 @@ def test_fullsize_duplicate_frames_and_linearity(gpu):
         assert (lhs - rhs).abs().max().item() < 1e-3
 
 
+def test_fullsize_translation_equivariance(gpu):
+    """A sparse conv net commutes with translations of the voxel grid by multiples of its coarsest tensor stride (16 for the
+    4-level MinkUNet).  The shifted Cfg-2 frame gets a different canonical row order (rows are sorted by a Morton key of the
+    biased coordinates), different hash tables, tiles and plans - and every voxel's logits must still be the same bits,
+    because an output element's fma chain is ordered by (kernel offset, channel) only.  Full size, no oracle needed."""
+    import mrcc_amd
+    from mrcc_amd import MinkowskiEngine as ME
+    from mrcc_amd.model.backbone.minkunet import MinkUNet14A
+
+    def by_coordinate(c):
+        c = c.cpu().numpy()
+        return np.lexsort((c[:, 3], c[:, 2], c[:, 1], c[:, 0]))
+
+    torch.manual_seed(0)
+    net = MinkUNet14A(3, 16).to(gpu).eval()
+    pts, rgb, _ = mrcc_amd.synth.gen_room(200_000, 2.4, 0)
+    with torch.no_grad():
+        x = ME.TensorField(torch.from_numpy(rgb), torch.from_numpy(_coords(pts, 50)), device=gpu).sparse()
+        base = net(x)
+        ia = by_coordinate(x.C)  # a translation keeps the lexicographic order
+        ref_bits = base.F.view(torch.int32).cpu().numpy()[ia]
+        for shift in ((32, -48, 16), (-1024, 2048, -16)):
+            c = x.C.clone()
+            c[:, 1:] += torch.tensor(shift, dtype=c.dtype, device=c.device)
+            xs = ME.SparseTensor(x.F.clone(), coordinates=c, device=gpu)
+            ib = by_coordinate(xs.C)
+            assert np.array_equal(xs.C.cpu().numpy()[ib], c.cpu().numpy()[ia])
+            assert not torch.equal(xs.C, c)  # the canonical order really differs: the check below is not vacuous
+            assert torch.equal(xs.F.cpu()[ib], x.F.cpu()[ia])
+            out = net(xs)
+            assert np.array_equal(out.F.view(torch.int32).cpu().numpy()[ib], ref_bits), shift
+            for ts in (2, 4, 8, 16):
+                assert x.coordinate_manager.stride_map(ts).V == xs.coordinate_manager.stride_map(ts).V
+
+
 def test_alive_unet_and_vote_head(gpu):
     import mrcc_amd
     from mrcc_amd import MinkowskiEngine as ME
