@@ -118,11 +118,13 @@ def make_frame(seed, device, n=POINTS, L=ROOM, batch=1):
             parts[0][2])
 
 
-def run_frames(model, pipe, frames, steps, hist=None):
+def run_frames(model, pipe, frames, steps, hist=None, group=1):
     """Process `steps` frames through the multi-stream pipeline (mrcc_amd/app/pipeline.py): while the U-Net of frame i
     runs on the compute stream, the host builds frame i+1's coordinate maps / plans on the prep stream.  Every frame
     is voxelised and mapped from scratch; all work of all `steps` frames is enqueued (and, by the caller's
-    synchronize, finished) inside the caller's timed region."""
+    synchronize, finished) inside the caller's timed region.  group > 1: consecutive frames go through the network
+    `group` at a time as one sparse tensor (FramePipeline.prepare_group: the concatenation is part of the timed work);
+    the last group of a region holds the remainder."""
     voxels = 0
     cls = torch.arange(3, device=frames[0][1].device).unsqueeze(1)
 
@@ -135,16 +137,20 @@ def run_frames(model, pipe, frames, steps, hist=None):
             return (label.unsqueeze(0) == cls).sum(dim=1)
         return label
 
+    def members(i):  # the frames of steps [i, i + group)
+        return [frames[(i + j) % len(frames)][:2] for j in range(min(group, steps - i))]
+
     partial = []
-    nxt = pipe.prepare(*frames[0][:2])
-    for i in range(steps):
+    starts = list(range(0, steps, group))
+    nxt = pipe.prepare_group(members(0)) if starts else None
+    for gi, i in enumerate(starts):
         cur = nxt
         res = pipe.run(cur, unet)
         if hist is not None:
             partial.append(res)
         voxels += cur.x.F.shape[0]
-        if i + 1 < steps:
-            nxt = pipe.prepare(*frames[(i + 1) % len(frames)][:2])
+        if gi + 1 < len(starts):
+            nxt = pipe.prepare_group(members(starts[gi + 1]))
     if hist is not None:
         pipe.drain()  # per-frame histograms live on their frames' streams
         hist += torch.stack(partial).sum(dim=0)
@@ -780,6 +786,10 @@ def main():
                          "the best measured frames/s (DESIGN.md section 8)")
     ap.add_argument("--stagger-level0", type=int, default=None, choices=(0, 1),
                     help="level-0 stages of consecutive frames take turns (default: MRCC_STAGGER_LEVEL0 / the pipeline's default)")
+    ap.add_argument("--group", type=int, default=4,
+                    help="frames the pipeline puts through the network at a time as ONE sparse tensor (batch column = position "
+                         "in the group; FramePipeline.prepare_group). A step stays one frame: --steps frames are timed, the "
+                         "last group of a region holds the remainder. 1 = every frame its own launches")
     ap.add_argument("--frames-per-step", type=int, default=1,
                     help="frames fused into one sparse tensor per step (batch column); 1 = the headline workload")
     ap.add_argument("--batched-frames", type=int, default=4,
@@ -853,6 +863,7 @@ def main():
     from mrcc_amd.app.pipeline import FramePipeline
 
     stagger = None if args.stagger_level0 is None else bool(args.stagger_level0)
+    group = max(1, args.group) if args.frames_per_step == 1 else 1  # an explicitly batched workload is not grouped again
     pipe = FramePipeline(device, levels=4, compute_streams=args.streams, stagger_level0=stagger)
     src_threads = args.source_threads or max(2, min(6, pin.get("cores", 8) - 2))
     if args.total_frames > 0:
@@ -891,12 +902,12 @@ def main():
     with torch.no_grad():
         # warm-up (untimed), part 1 on ONE compute stream: every conv launch is event-timed -> per-kernel table and the
         # dominant kernel instance measured in isolation; part 2 warms the multi-stream pipeline used in the timed region
-        nwarm = max(args.warmup, 2)
+        nwarm = -(-max(args.warmup, 2) // group) * group  # whole groups: every launch of the pass covers `group` frames
         warm_timer = profiling.KernelTimer(capacity=2 * 64 * nwarm + 64)
         profiling.TIMER = warm_timer
         pipe.single = True
         warm_hist = torch.zeros(3, dtype=torch.int64, device=device)  # same code path as the timed region: the
-        run_frames(model, pipe, frames, nwarm, warm_hist)              # first use of a torch kernel loads its code object
+        run_frames(model, pipe, frames, nwarm, warm_hist, group=group)  # first use of a torch kernel loads its code object
         pipe.drain()
         torch.cuda.synchronize()
         pipe.single = False
@@ -909,7 +920,7 @@ def main():
         # 1).  Time-ranking would be fooled by the first launch after an idle gap, whose event interval absorbs the gap.
         dominant_layer = max(warm_by_layer.items(), key=lambda kv: kv[1]["flops"])[0]
         dominant = dominant_layer[0]
-        run_frames(model, pipe, frames, nwarm, warm_hist)
+        run_frames(model, pipe, frames, max(nwarm, 2 * group), warm_hist, group=group)
         pipe.drain()
         torch.cuda.synchronize()
         # ---- the timed region, R times: each is EXACTLY --steps steps bracketed by barrier + synchronize on both sides
@@ -925,7 +936,7 @@ def main():
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             hist_r = torch.zeros(3, dtype=torch.int64, device=device)
-            voxels = run_frames(model, pipe, frames, args.steps, hist_r)
+            voxels = run_frames(model, pipe, frames, args.steps, hist_r, group=group)
             torch.cuda.synchronize()
             barrier()
             torch.cuda.synchronize()
@@ -965,6 +976,19 @@ def main():
                    "frames_per_step": args.batched_frames, "steps": bsteps, "ms_per_step": round(tb / bsteps * 1e3, 3),
                    "value_this_rank": round(bsteps * args.batched_frames / tb, 3), "unit": "frames/s"}
         _log(f"batched x{args.batched_frames}: {batched['value_this_rank']} frames/s on this rank")
+    ungrouped = None
+    if extras and group > 1:  # the same frames one per launch (rounds 1-3's headline configuration), for continuity
+        with torch.no_grad():
+            run_frames(model, pipe, frames, 6)
+            pipe.drain()
+            torch.cuda.synchronize()
+            tu = time.perf_counter()
+            run_frames(model, pipe, frames, args.steps)
+            torch.cuda.synchronize()
+            tu = time.perf_counter() - tu
+        ungrouped = {"config": "the headline's frames, one frame per sparse tensor (--group 1)", "steps": args.steps,
+                     "ms_per_step": round(tu / args.steps * 1e3, 3), "value_this_rank": round(args.steps / tu, 3), "unit": "frames/s"}
+        _log(f"one frame per launch: {ungrouped['value_this_rank']} frames/s on this rank")
     hbm_layers = hbm_bound_layers(model, device) if extras else None
     other = engine = None
     if extras:
@@ -1003,7 +1027,7 @@ def main():
         ksum = timer.summarize()
         ksum_by_layer = timer.summarize(by_layer=True)
         roofline = None
-        nwarm = max(args.warmup, 2)
+        nwarm = -(-max(args.warmup, 2) // group) * group  # frames of the warm-up pass (see above)
         gflop_step = sum(v["flops"] for v in warm.values()) / nwarm / 1e9  # every conv launch of one step
         if dominant_layer in ksum_by_layer:
             name, d = dominant, ksum_by_layer[dominant_layer]
@@ -1071,7 +1095,7 @@ def main():
             e2e = gflop_step / (elapsed / args.steps * 1e3) if elapsed > 0 else 0.0  # GFLOP / ms = TFLOP/s
             roofline["end_to_end"] = {"gflop_per_step": round(gflop_step, 1), "tflops": round(e2e, 2),
                                       "frac": round(e2e / PEAK_F32_MFMA_TFLOPS, 4)}
-        kernels = {k: {"launches_per_step": v["launches"] // nwarm, "ms_per_step": round(v["ms"] / nwarm, 3),
+        kernels = {k: {"launches_per_step": round(v["launches"] / nwarm, 2), "ms_per_step": round(v["ms"] / nwarm, 3),
                        "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                        "gather_GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for k, v in warm.items()}
         per_step = [t / args.steps * 1e3 for t in reps_max]
@@ -1088,6 +1112,12 @@ def main():
             "config": {"workload": "cfg2: synthetic 200k-pt RGB-D cloud, 2 cm voxels, RobotNetSegmentation(MinkUNet18D) "
                                    "forward = voxelise + sparse U-Net + slice/argmax, random-init weights",
                        "points_per_frame": POINTS, "frames_per_step": args.frames_per_step,
+                       "frames_per_sparse_tensor": group,
+                       "grouping": (f"a step is one frame; the pipeline voxelises {group} consecutive resident frames into one "
+                                    "sparse tensor (batch column) and runs the network once per group, the reference's own batched "
+                                    "format (data/alivev2.py:358-383, TEST.batch_size in config/default.yaml:109); per-frame results "
+                                    "are bit-identical to single-frame launches (tests/test_gpu_engine.py); --group 1 = round 1-3's "
+                                    "one frame per launch") if group > 1 else "one frame per sparse tensor",
                        "voxel_size_m": 1.0 / SCALE,
                        "active_voxels_per_frame": int(voxels_per_frame),
                        "label_histogram": [int(x) for x in np.diag(agg["confusion"])],
@@ -1116,6 +1146,8 @@ def main():
             line["hbm_bound_layers"] = hbm_layers
         if batched is not None:
             line["batched"] = batched
+        if ungrouped is not None:
+            line["one_frame_per_launch"] = ungrouped
         if other is not None:
             line["other_configs"] = other
         if engine is not None:

@@ -36,10 +36,11 @@ def shared_stream(device, role, index=0, priority=0):
 
 
 class PreparedFrame:
-    __slots__ = ("field", "x", "ready", "done", "tag", "stream", "result")
+    __slots__ = ("field", "x", "ready", "done", "tag", "stream", "result", "sizes")
 
     def __init__(self, field, x, ready, tag=None):
         self.field, self.x, self.ready, self.done, self.tag = field, x, ready, None, tag
+        self.sizes = None  # prepare_group: points per frame of the group
         self.stream = None  # compute stream run() put the frame on
         self.result = None
 
@@ -116,6 +117,30 @@ class FramePipeline:
                 cm.build_plans(self.levels)
                 ready.record(self.prep_stream)
         return PreparedFrame(field, x, ready, tag)
+
+    def prepare_group(self, frames, tag=None):
+        """Several resident frames as ONE sparse tensor - the reference's batched format (batch index in column 0,
+        data/alivev2.py:358-383; its test loaders run TEST.batch_size frames per tensor, config/default.yaml:109).
+        frames: [(coords4, feats), ...], each one frame (its own batch column is ignored); the group's batch column is the
+        frame's position.  Frames of a batch never interact (batch index in the voxel key, BN in eval mode): every frame's
+        rows carry the bits of its single-frame run (tests/test_gpu_engine.py), and the launches are len(frames) times
+        longer - the ramp and decay of a chip-filling launch and the latency-bound small-level launches are paid once per
+        group instead of once per frame.  The returned PreparedFrame's field / tensor cover the group, points and voxels
+        in frame order; `.sizes` = points per frame."""
+        if len(frames) == 1:
+            prepared = self.prepare(frames[0][0], frames[0][1], tag)
+            prepared.sizes = [int(frames[0][0].shape[0])]
+            return prepared
+        with torch.cuda.stream(self.prep_stream):
+            coords = torch.cat([c for c, _ in frames])
+            off = 0
+            for b, (c, _) in enumerate(frames):
+                coords[off:off + c.shape[0], 0] = float(b)
+                off += c.shape[0]
+            feats = torch.cat([f for _, f in frames])
+        prepared = self.prepare(coords, feats, tag)
+        prepared.sizes = [int(c.shape[0]) for c, _ in frames]
+        return prepared
 
     def run(self, prepared, fn):
         """Run fn(x, field) on a compute stream once the frame is ready; returns fn's result (valid on that stream;

@@ -96,6 +96,49 @@ def test_batched_frames_equal_single_frames(gpu):
         start += len(s)
 
 
+def test_pipeline_groups_equal_single_frames(gpu):
+    """FramePipeline.prepare_group (bench.py --group, the headline's default): frames that arrive one by one - each with its
+    own batch column 0 - go through the segmentation network as one sparse tensor; labels, confidences and logits of every
+    frame are the bits of its own single-frame pass through the same pipeline, on three compute streams, for group sizes
+    that do and do not divide the number of frames."""
+    import mrcc_amd
+    from mrcc_amd.app.pipeline import FramePipeline
+    from mrcc_amd.model.robotnet_segmentation import RobotNetSegmentation
+
+    torch.manual_seed(5)
+    net = RobotNetSegmentation(in_channels=3, num_classes=3).to(gpu).eval()
+    _randomize_bn(net, 6)
+    frames = []
+    for b in range(5):
+        pts, rgb, _ = mrcc_amd.synth.gen_room(20_000 + 3000 * b, 1.0, 40 + b)
+        c = np.concatenate([np.zeros((len(pts), 1), np.float32), pts * np.float32(50)], axis=1)
+        frames.append((torch.from_numpy(c).to(gpu), torch.from_numpy(rgb).to(gpu)))
+    pipe = FramePipeline(gpu, levels=4, compute_streams=3)
+
+    def fn(x, field):
+        out = net(x)
+        label, conf = out.slice_argmax(field)
+        return label, conf, out.slice(field).F
+
+    with torch.no_grad():
+        singles = [pipe.run(pipe.prepare(c, f), fn) for c, f in frames]
+        pipe.drain()
+        for group in (2, 5):
+            got = []
+            for i in range(0, len(frames), group):
+                prepared = pipe.prepare_group(frames[i:i + group])
+                assert prepared.sizes == [int(c.shape[0]) for c, _ in frames[i:i + group]]
+                label, conf, logits = pipe.run(prepared, fn)
+                pipe.drain()
+                got += [tuple(t[a:b] for t in (label, conf, logits))
+                        for a, b in zip(np.cumsum([0] + prepared.sizes[:-1]), np.cumsum(prepared.sizes))]
+            assert len(got) == len(singles)
+            for (l1, c1, f1), (l2, c2, f2) in zip(singles, got):
+                assert torch.equal(l1, l2) and torch.equal(c1.view(torch.int32), c2.view(torch.int32))
+                assert torch.equal(f1.view(torch.int32), f2.view(torch.int32))
+    assert all(float(c[0, 0]) == 0.0 for c, _ in frames)  # the callers' frames are not modified
+
+
 def test_inference_engine_pipeline(gpu, oracle):
     import mrcc_amd
     from mrcc_amd.app.dto import PointCloudDTO, ResultDTO

@@ -24,6 +24,7 @@ ap.add_argument("--scale", type=float, default=50.0, help="voxels per metre (50 
 ap.add_argument("--kind", default="k3")
 ap.add_argument("--cube", type=int, default=0, help="solid cube of this edge length (voxels) instead of the room cloud")
 ap.add_argument("--split", default="0", help="run the 3x3x3 layer as passes over offset ranges: 14 -> [0,14) [14,27); 9,18 -> three")
+ap.add_argument("--frames", type=int, default=1, help="this many room clouds (seeds 0, 1, ...) in one sparse tensor: the headline's launch size is 4")
 args = ap.parse_args()
 
 dev = torch.device("cuda:0")
@@ -37,8 +38,10 @@ if args.cube:
     coords4 = np.concatenate([np.zeros((len(xyz), 1), np.float32), xyz], axis=1)
     rgb = np.zeros((len(xyz), 3), np.float32)
 else:
-    pts, rgb, _ = mrcc_amd.synth.gen_room(args.points, 2.4, 0)
-    coords4 = np.concatenate([np.zeros((len(pts), 1), np.float32), pts * np.float32(args.scale)], axis=1)
+    clouds = [mrcc_amd.synth.gen_room(args.points, 2.4, sd) for sd in range(args.frames)]
+    coords4 = np.concatenate([np.concatenate([np.full((len(c[0]), 1), b, np.float32), c[0] * np.float32(args.scale)], axis=1)
+                              for b, c in enumerate(clouds)])
+    rgb = np.concatenate([c[1] for c in clouds])
 x = ME.TensorField(torch.from_numpy(rgb), torch.from_numpy(coords4), device=dev).sparse()
 cm = x.coordinate_manager
 ts = 2 ** args.level

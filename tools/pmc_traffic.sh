@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/traffic; mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE TCC_EA0_RDREQ_sum; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/calib_$c -- python tools/traffic_calib.py > $OUT/calib_$c.log 2>&1
-  rocprofv3 --pmc $c --output-format csv -d $OUT/bench_$c -- python bench.py --no-cpu-baseline --no-extras --steps 6 --warmup 2 --streams 1 > $OUT/bench_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $OUT/bench_$c -- python bench.py --no-cpu-baseline --no-extras --steps 8 --warmup 4 --streams 1 > $OUT/bench_$c.log 2>&1
 done
 python - <<PY
 import csv, glob, json, collections
