@@ -31,7 +31,7 @@ known = raw["known"]
 ff = known["read_bytes"] / (cal["FETCH_SIZE"] * 1024)
 wf = known["write_bytes"] / (cal["WRITE_SIZE"] * 1024)
 out = {
-    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --steps 6 --warmup 2 --streams 1`",
+    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --no-cpu-baseline --no-extras --steps 8 --warmup 4 --streams 1` (4 frames per sparse tensor: the default --group)",
     "calibration": {"kernel": fold(cal_name), "known_read_bytes": known["read_bytes"],
                     "known_write_bytes": known["write_bytes"], "FETCH_SIZE_KB": cal["FETCH_SIZE"],
                     "WRITE_SIZE_KB": cal["WRITE_SIZE"], "fetch_factor": round(ff, 4), "write_factor": round(wf, 4),
