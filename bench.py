@@ -477,7 +477,7 @@ def _median(xs):
     return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
 
 
-def strong_scaling_block(model, device, rank, world, total_frames, streams, threads, barrier):
+def strong_scaling_block(model, device, rank, world, total_frames, streams, threads, barrier, group=1):
     """Cfg-4 (BASELINE configs[3]): a FIXED job of `total_frames` frames sharded over the ranks (rank r takes seeds
     r, r + world, ...: app/sharding.py), host arrays in -> labels out.  Inside the timed region, per rank: background
     host threads produce the rank's frames in order (synthetic generation stands in for the reference's per-frame
@@ -492,7 +492,7 @@ def strong_scaling_block(model, device, rank, world, total_frames, streams, thre
     def stage(x, field):
         return model(x).slice_argmax(field, with_conf=False)[0]
 
-    stream = HostFrameStream(device, SCALE, stage, None, compute_streams=streams)
+    stream = HostFrameStream(device, SCALE, stage, None, compute_streams=streams, group=group)  # group: frames per sparse tensor
 
     def source(which):
         return ordered_prefetch(lambda sd: mrcc_amd.synth.gen_room(POINTS, ROOM, sd)[:2], which, threads=threads,
@@ -722,13 +722,24 @@ def engine_block(device):
         got = list(eng.predict_segmentation_stream(iter(frames)))
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / len(frames) * 1e3
+        for _ in range(2):
+            list(eng.predict_segmentation_stream(iter(frames[:16]), group=4))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        got4 = list(eng.predict_segmentation_stream(iter(frames), group=4))
+        torch.cuda.synchronize()
+        ms4 = (time.perf_counter() - t0) / len(frames) * 1e3
         out = {"workload": "engine: InferenceEngine.predict_segmentation_stream, host numpy in -> labels out "
                            "(H2D, voxelise, U-Net, slice/argmax, EE cluster rule, D2H inside the timed region), 200k-pt frames",
                "value": round(1e3 / ms, 3), "unit": "frames/s", "ms_per_frame": round(ms, 3), "frames_timed": len(frames),
                "per_frame_predict_segmentation_ms": round(sync_ms, 3),
                "per_frame_predict_segmentation_ms_min_max": [round(min(lat), 3), round(max(lat), 3)],
                "within_budget": {"per_frame_ms_le_21": bool(sync_ms <= 21.0), "stream_ms_le_20": bool(ms <= 20.0)},
-               "labels_equal_predict_segmentation": bool(np.array_equal(got[1], ref) and np.array_equal(got[5], ref))}
+               "labels_equal_predict_segmentation": bool(np.array_equal(got[1], ref) and np.array_equal(got[5], ref)),
+               "stream_group4": {"what": "predict_segmentation_stream(group=4): four consecutive frames per sparse tensor, labels "
+                                         "delivered a group at a time", "value": round(1e3 / ms4, 3), "unit": "frames/s",
+                                 "ms_per_frame": round(ms4, 3),
+                                 "labels_equal": bool(all(np.array_equal(a, b) for a, b in zip(got4, got)))}}
         # ---- whole predict() on labelled scenes
         mrcc_amd.synth.wire_color_keyed_labels(eng._segmentation_model)
         scenes = [mrcc_amd.synth.gen_scene(sd, n_bg=POINTS - 4000 - 4096, n_arm=4000, n_ee=4096, room=ROOM, keyed_colors=True)
@@ -750,6 +761,16 @@ def engine_block(device):
         res = list(eng.predict_stream(iter(seq)))
         torch.cuda.synchronize()
         full_ms = (time.perf_counter() - t0) / len(seq) * 1e3
+        for _ in range(2):
+            list(eng.predict_stream(iter(seq[:12]), seg_group=4))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res4 = list(eng.predict_stream(iter(seq), seg_group=4))
+        torch.cuda.synchronize()
+        full4_ms = (time.perf_counter() - t0) / len(seq) * 1e3
+        same4 = all(np.array_equal(a.segmentation, b.segmentation) and np.array_equal(a.ee_pose, b.ee_pose) and
+                    np.array_equal(a.key_points_pose, b.key_points_pose) and np.array_equal(a.base_pose, b.base_pose)
+                    for a, b in zip(res4, res))
         same = all(np.array_equal(r.segmentation, refs[i % 4].segmentation) and r.ee_pose is not None and
                    np.array_equal(r.ee_pose, refs[i % 4].ee_pose) and np.array_equal(r.key_points_pose, refs[i % 4].key_points_pose)
                    and np.array_equal(r.base_pose, refs[i % 4].base_pose) for i, r in enumerate(res))
@@ -759,6 +780,9 @@ def engine_block(device):
                         "segmentation -> crop -> rotation net -> translation -> key-point net -> selection -> Kabsch -> base poses",
             "stream": {"value": round(1e3 / full_ms, 3), "unit": "frames/s", "ms_per_frame": round(full_ms, 3),
                        "frames_timed": len(seq), "pose_group": 4},
+            "stream_seg_group4": {"what": "predict_stream(seg_group=4): the segmentation stage on groups of four frames too",
+                                  "value": round(1e3 / full4_ms, 3), "unit": "frames/s", "ms_per_frame": round(full4_ms, 3),
+                                  "results_equal": bool(same4)},
             "per_frame": {"value": round(1e3 / _median(lat), 3), "unit": "frames/s", "ms_per_frame": round(_median(lat), 3),
                           "ms_min_max": [round(min(lat), 3), round(max(lat), 3)]},
             "stream_over_segmentation_stream": round(ms / full_ms, 3),
@@ -869,7 +893,8 @@ def main():
     if args.total_frames > 0:
         # ------------------------------------------------------------------------------------------------ strong mode
         with torch.no_grad():
-            rec = strong_scaling_block(model, device, rank, world, args.total_frames, args.streams, src_threads, barrier)
+            rec = strong_scaling_block(model, device, rank, world, args.total_frames, args.streams, src_threads, barrier,
+                                       group=group)
         agg = gather_metrics({"frames": rec["frames"], "elapsed": rec["elapsed"], "confusion": np.diag(rec["hist"]),
                               "seed_sum": rec["seed_sum"],
                               "per_rank": dict({f"host_{k}_ms": v for k, v in rec["host_ms_per_frame"].items()},
@@ -886,6 +911,7 @@ def main():
                                            "host threads per rank), pinned staging, H2D, voxelise, RobotNetSegmentation"
                                            "(MinkUNet18D), slice/argmax, D2H all inside the timed region",
                                "total_frames": args.total_frames, "per_rank_frames": agg["per_rank_frames"],
+                               "frames_per_sparse_tensor": group,
                                "points_per_frame": POINTS, "label_histogram": [int(v) for v in np.diag(agg["confusion"])],
                                "host_ms_per_frame_rank0": rec["host_ms_per_frame"], "host_placement": pin,
                                "per_rank_elapsed_s": [round(x, 4) for x in agg["per_rank_elapsed"]],
@@ -999,7 +1025,8 @@ def main():
     if not args.no_extras and args.strong_frames > 0 and args.frames_per_step == 1:
         _log(f"strong-scaling block: {args.strong_frames} frames over {world} rank(s), {src_threads} source threads per rank")
         with torch.no_grad():
-            strong = strong_scaling_block(model, device, rank, world, args.strong_frames, args.streams, src_threads, barrier)
+            strong = strong_scaling_block(model, device, rank, world, args.strong_frames, args.streams, src_threads, barrier,
+                                          group=group)
     if extras:
         # LAST: Cfg-3 holds 60-77 GiB for a moment and the block returns its memory to the driver (empty_cache); whatever runs
         # after such an episode is ~10 % slower for the rest of the process (engine stream 70.2 -> 62.6 frames/s after a 20 GB
@@ -1137,7 +1164,8 @@ def main():
                             "and D2H inside the timed region",
                 "scaling": "strong", "total_frames": args.strong_frames, "value": round(args.strong_frames / t_strong, 3),
                 "unit": "frames/s", "seconds": round(t_strong, 3), "frames_rank0": strong["frames"],
-                "source_threads_per_rank": src_threads, "host_ms_per_frame_rank0": strong["host_ms_per_frame"],
+                "source_threads_per_rank": src_threads, "frames_per_sparse_tensor": group,
+                "host_ms_per_frame_rank0": strong["host_ms_per_frame"],
                 "per_rank": {k[len("strong_"):]: [round(x, 3) for x in v] for k, v in agg["per_rank"].items()
                              if k.startswith("strong_")},
                 "note": "same total job at every N: value(N) / value(1) is the strong-scaling speed-up; per_rank: every "

@@ -154,20 +154,22 @@ class InferenceEngine:
             self._one_frame_stream = st
         return st.run_one(points, rgb)
 
-    def predict_segmentation_stream(self, frames, compute_streams=3):
+    def predict_segmentation_stream(self, frames, compute_streams=3, group=1):
         """Streaming form of predict_segmentation for a sequence of frames (the reference's consumer is the per-frame
         loop of app/main.py:432-456): `frames` yields (points, rgb) host arrays, the generator yields the label arrays in
         order, each IDENTICAL to predict_segmentation(points, rgb) - while frame i's network runs, frame i+1 is staged
         through pinned memory, uploaded and voxelised, and frame i-1's cluster rule and label download complete
-        (app/pipeline.py HostFrameStream).  Engine-path throughput: see bench.py's `engine` block."""
+        (app/pipeline.py HostFrameStream).  group > 1: that many consecutive frames share one sparse tensor (the
+        reference's batched format, data/alivev2.py:358-383) - the same labels, launches `group` times longer (≈ 4 % more
+        frames/s at 4), results delivered a group at a time.  Engine-path throughput: see bench.py's `engine` block."""
         from .pipeline import HostFrameStream
 
         # one stream object per configuration, kept: its pinned staging buffers and HIP streams are expensive to create
-        key = (compute_streams, self._config.INFERENCE.SEGMENTATION.scale)
+        key = (compute_streams, self._config.INFERENCE.SEGMENTATION.scale, max(1, int(group)))
         streams = self.__dict__.setdefault("_seg_streams", {})
         if key not in streams:
             streams[key] = HostFrameStream(self.device, key[1], self._segment, self._largest_ee_cluster_rule,
-                                           compute_streams=compute_streams)
+                                           compute_streams=compute_streams, group=key[2])
         return streams[key].run(frames)
 
     # ---- pose stages on end-effector crops (reference :437-559), one or several crops per network run ---------------
@@ -351,7 +353,7 @@ class InferenceEngine:
         seg = self.predict_segmentation(data.points, rgb)
         return self._pose_collect(self._pose_enqueue([(data, rgb, seg)], one_frame=True))[0]
 
-    def predict_stream(self, frames, compute_streams=3, group=4, pose_thread=True):
+    def predict_stream(self, frames, compute_streams=3, group=4, pose_thread=True, seg_group=1):
         """predict() over a sequence of PointCloudDTOs, everything pipelined: the segmentation stage across frames
         (predict_segmentation_stream), and the pose stages (reference :304-319: rotation network, translation, key-point
         network, key-point selection, Kabsch, base poses) for GROUPS of `group` consecutive frames - their end-effector crops
@@ -375,7 +377,8 @@ class InferenceEngine:
                 yield data.points, rgb
 
         cur, pending = [], collections.deque()
-        seg_stream = self.predict_segmentation_stream(inputs(), compute_streams=compute_streams)
+        # seg_group > 1: the segmentation stage also runs groups of frames per sparse tensor (predict_segmentation_stream)
+        seg_stream = self.predict_segmentation_stream(inputs(), compute_streams=compute_streams, group=seg_group)
         if not pose_thread:
             for seg in seg_stream:
                 data, rgb = window.popleft()

@@ -222,14 +222,19 @@ class HostFrameStream:
     bit-identical to the synchronous path: the same kernels run on the same data, only their interleaving changes."""
 
     def __init__(self, device, scale, stage, finish=None, levels=4, compute_streams=3, depth=None, stagger_level0=None,
-                 one_frame=False):
+                 one_frame=False, group=1):
         self.device = torch.device(device)
         self.scale = scale
         self.stage, self.finish = stage, finish
         self.pipe = FramePipeline(self.device, levels=levels, compute_streams=compute_streams, stagger_level0=stagger_level0,
                                   one_frame=one_frame)
         self.depth = depth or max(2, compute_streams)
-        self._slots = [_HostSlot() for _ in range(self.depth + 2)]
+        # group > 1 (run() only): that many consecutive frames go through `stage` as ONE sparse tensor (batch column =
+        # position in the group, as FramePipeline.prepare_group; frames never interact, so every frame's labels are the bits
+        # of its own pass) - launches `group` times longer, results delivered a group at a time; `finish` and the download
+        # stay per frame
+        self.group = max(1, int(group))
+        self._slots = [_HostSlot() for _ in range((self.depth + 2) * self.group)]
         self._n = 0
         # host wall time per phase, summed over frames (perf_counter deltas; tools/engine_stream_phases.py prints them)
         self.host_s = {"stage": 0.0, "prepare": 0.0, "launch": 0.0, "finalize": 0.0, "frames": 0}
@@ -268,6 +273,78 @@ class HostFrameStream:
         self.host_s["frames"] += 1
         return out
 
+    def _upload_and_prepare_group(self, members):
+        """members: [(points, rgb), ...] host arrays of consecutive frames -> one PreparedFrame over all of them; its tag is
+        the list of (slot, device points, n) per frame."""
+        import numpy as np
+
+        if len(members) == 1:
+            out = self._upload_and_prepare(*members[0])
+            out.tag = [out.tag]
+            return out
+        t0 = time.perf_counter()
+        prep = self.pipe.prep_stream
+        sizes = [len(p) for p, _ in members]
+        first_rgb = members[0][1]
+        channels = first_rgb.shape[1] if torch.is_tensor(first_rgb) else np.asarray(first_rgb).shape[1]
+        with torch.cuda.stream(prep):
+            coords4 = torch.empty((sum(sizes), 4), dtype=torch.float32, device=self.device)
+            feats = torch.empty((sum(sizes), channels), dtype=torch.float32, device=self.device)
+        tags, off, t_stage = [], 0, 0.0
+        for b, (points, rgb) in enumerate(members):
+            slot = self._slots[self._n % len(self._slots)]
+            self._n += 1
+            if slot.uploaded is not None:
+                slot.uploaded.synchronize()
+            n = sizes[b]
+            slot.reserve(n, channels)
+            np.copyto(slot.pts.numpy()[:n], np.asarray(points), casting="same_kind")
+            with torch.cuda.stream(prep):  # the points are on their way while the colours are staged
+                d_pts = slot.pts[:n].to(self.device, non_blocking=True)
+                rows = coords4[off:off + n]
+                rows[:, 0] = float(b)
+                torch.mul(d_pts, self.scale, out=rows[:, 1:])
+            if torch.is_tensor(rgb):
+                slot.rgb[:n].copy_(rgb)
+            else:
+                np.copyto(slot.rgb.numpy()[:n], np.asarray(rgb), casting="same_kind")
+            with torch.cuda.stream(prep):
+                feats[off:off + n].copy_(slot.rgb[:n], non_blocking=True)
+                slot.uploaded = torch.cuda.Event()
+                slot.uploaded.record(prep)
+            tags.append((slot, d_pts, n))
+            off += n
+        t1 = time.perf_counter()
+        out = self.pipe.prepare(coords4, feats, tag=tags)
+        out.sizes = sizes
+        t2 = time.perf_counter()
+        self.host_s["stage"] += t1 - t0
+        self.host_s["prepare"] += t2 - t1
+        self.host_s["frames"] += len(members)
+        return out
+
+    def _finalize_group(self, prepared):
+        """per frame of the group: `finish` on its slice of the labels, download; one wait for the whole group"""
+        import numpy as np
+
+        t0 = time.perf_counter()
+        stream = prepared.stream if prepared.stream is not None else torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(stream):
+            off = 0
+            for slot, d_pts, n in prepared.tag:
+                label = prepared.result[off:off + n]
+                if self.finish is not None:
+                    label = self.finish(label, d_pts)
+                slot.labels[:n].copy_(label, non_blocking=True)
+                off += n
+            done = torch.cuda.Event()
+            done.record(stream)
+        done.synchronize()
+        outs = [np.array(slot.labels.numpy()[:n]) for slot, _, n in prepared.tag]
+        prepared.result = prepared.tag = None
+        self.host_s["finalize"] += time.perf_counter() - t0
+        return outs
+
     def _launch(self, prepared):
         t0 = time.perf_counter()
         prepared.result = self.pipe.run(prepared, self.stage)
@@ -305,6 +382,26 @@ class HostFrameStream:
         """frames: iterable of (points [N,3], rgb [N,C]) host arrays -> generator of int64 label arrays, in order."""
         pending = collections.deque()
         it = iter(frames)
+        if self.group > 1:
+            import itertools
+
+            def take():
+                members = list(itertools.islice(it, self.group))
+                return self._upload_and_prepare_group(members) if members else None
+
+            with torch.no_grad():
+                nxt = take()
+                while nxt is not None:
+                    cur = nxt
+                    self._launch(cur)
+                    pending.append(cur)
+                    nxt = take()
+                    while len(pending) >= self.depth:
+                        yield from self._finalize_group(pending.popleft())
+                while pending:
+                    yield from self._finalize_group(pending.popleft())
+                self.pipe.drain()
+            return
         try:
             first = next(it)
         except StopIteration:

@@ -457,6 +457,13 @@ def test_engine_streaming_equals_per_frame_predict(gpu):
             for g, w in zip(got, want):
                 assert g.dtype == w.dtype and np.array_equal(g, w)
         assert list(eng.predict_segmentation_stream(iter([]))) == []
+        # groups of frames per sparse tensor (7 frames: groups of 3 + 3 + 1, of 4 + 3, one of 7): the same labels, in order
+        for seg_group in (3, 4, 8):
+            got = list(eng.predict_segmentation_stream(iter(frames), compute_streams=3, group=seg_group))
+            assert len(got) == len(want)
+            for g, w in zip(got, want):
+                assert g.dtype == w.dtype and np.array_equal(g, w)
+        assert list(eng.predict_segmentation_stream(iter([]), group=4)) == []
         # the whole predict() flow: per frame, streamed in groups of 4 (7 frames: a full and a partial group), of 1 and of 3
         dtos = [PointCloudDTO(points=sc["points"], rgb=sc["rgb"], ee2base_pose=(None if i == 4 else sc["ee2base_pose"]))
                 for i, sc in enumerate(scenes)]
@@ -464,8 +471,8 @@ def test_engine_streaming_equals_per_frame_predict(gpu):
         assert ref[2].ee_pose is None and sum(r.ee_pose is not None for r in ref) == 6
         assert all(r.key_points_pose is not None for i, r in enumerate(ref) if i != 2)  # conf_threshold 0: six key points
         assert ref[4].base_pose is None and ref[3].base_pose is not None
-        for group in (4, 1, 3):
-            out = list(eng.predict_stream(iter(dtos), group=group))
+        for group, seg_group in ((4, 1), (1, 1), (3, 1), (4, 4), (2, 3)):
+            out = list(eng.predict_stream(iter(dtos), group=group, seg_group=seg_group))
             assert len(out) == len(ref)
             for o, r in zip(out, ref):
                 _same_result(o, r)
