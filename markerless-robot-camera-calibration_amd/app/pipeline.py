@@ -202,10 +202,13 @@ class _HostSlot:
 
     def reserve(self, n, channels):
         if self.rgb is None or n > self.cap or self.rgb.shape[1] != channels:
-            self.cap = max(n, int(self.cap * 1.25), 1)
-            self.pts = torch.empty((self.cap, 3), dtype=torch.float32).pin_memory()
-            self.rgb = torch.empty((self.cap, channels), dtype=torch.float32).pin_memory()
-            self.labels = torch.empty(self.cap, dtype=torch.int64).pin_memory()
+            # ONE pinned allocation per slot, carved into labels | points | colours: pinning is a driver call of milliseconds
+            # (two orders of magnitude more when processes share a GPU), so there are few of them and none per frame
+            self.cap = cap = max(n, int(self.cap * 1.25), 1)
+            buf = torch.empty(cap * (8 + 12 + 4 * channels), dtype=torch.uint8).pin_memory()
+            self.labels = buf[:8 * cap].view(torch.int64)
+            self.pts = buf[8 * cap:20 * cap].view(torch.float32).view(cap, 3)
+            self.rgb = buf[20 * cap:].view(torch.float32).view(cap, channels)
 
 
 class HostFrameStream:
@@ -238,6 +241,12 @@ class HostFrameStream:
         self._n = 0
         # host wall time per phase, summed over frames (perf_counter deltas; tools/engine_stream_phases.py prints them)
         self.host_s = {"stage": 0.0, "prepare": 0.0, "launch": 0.0, "finalize": 0.0, "frames": 0}
+
+    def preallocate(self, n, channels=3):
+        """Pin the staging buffers of every slot for frames of up to n points now (a warm-up step: otherwise each slot pins
+        its buffer at its first use, inside whatever is being timed)."""
+        for slot in self._slots:
+            slot.reserve(int(n), channels)
 
     def _upload_and_prepare(self, points, rgb):
         import numpy as np
