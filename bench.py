@@ -558,11 +558,16 @@ def other_configs_block(model, device, streams, checked):
         # the configuration as BASELINE words it - seg -> vote -> pose: the vote head (model/robotnet_vote.py:62-71) on the
         # same sparse tensor and one Kabsch solve per frame (the pose legs on the end-effector crop are parity-tested at
         # this size in tests/test_gpu_cfg.py; their networks see a few thousand points)
+        kp_ref1_d = torch.from_numpy(np.ascontiguousarray(kp_ref1, dtype=np.float64)).to(device)
+        kp_tgt1_d = torch.from_numpy(np.ascontiguousarray(kp_tgt1, dtype=np.float64)).to(device)
+
         def seg_vote_pose(x_, f_):
             lab_ = model(x_).slice_argmax(f_)[0]
             v_ = vote(x_).slice_argmax(f_)[0]
-            T.get_rigid_transform_3D_batched(kp_ref1, kp_tgt1, device=device)
-            return lab_, v_
+            # the solve is enqueued behind the networks on the frame's stream; its result stays on the device (a download
+            # here would block the host until the frame has finished, i.e. stop it from preparing the next one)
+            pose_ = T.get_rigid_transform_3D_batched(kp_ref1_d, kp_tgt1_d, device=device, as_tensors=True)
+            return lab_, v_, pose_
 
         def run5(n):
             nxt = pipe.prepare(*frames5[0][:2])

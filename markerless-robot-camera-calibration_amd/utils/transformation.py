@@ -19,12 +19,18 @@ def _dev(device):
     return torch.device("cuda" if device is None else device)
 
 
-def get_rigid_transform_3D_batched(reference, target, K=None, device=None):
-    """reference, target: [B, Kmax, 3]; K: int[B] points used per problem (default Kmax).
-    Returns (R [B,3,3], t [B,3], q_wxyz [B,4]) as float64 numpy arrays."""
+def get_rigid_transform_3D_batched(reference, target, K=None, device=None, as_tensors=False):
+    """reference, target: [B, Kmax, 3] (numpy, or float64 tensors already on the device); K: int[B] points used per problem
+    (default Kmax).  Returns (R [B,3,3], t [B,3], q_wxyz [B,4]) as float64 numpy arrays - or, as_tensors=True, as CUDA
+    tensors on the current stream with nothing downloaded and no host synchronisation (a caller inside a frame pipeline
+    collects them later)."""
     dev = _dev(device)
-    ref = torch.as_tensor(np.ascontiguousarray(reference, dtype=np.float64)).to(dev)
-    tgt = torch.as_tensor(np.ascontiguousarray(target, dtype=np.float64)).to(dev)
+    if torch.is_tensor(reference) and torch.is_tensor(target) and reference.is_cuda and target.is_cuda:
+        ref = reference.to(dtype=torch.float64).contiguous()
+        tgt = target.to(dtype=torch.float64).contiguous()
+    else:
+        ref = torch.as_tensor(np.ascontiguousarray(reference, dtype=np.float64)).to(dev)
+        tgt = torch.as_tensor(np.ascontiguousarray(target, dtype=np.float64)).to(dev)
     if ref.shape != tgt.shape or ref.dim() != 3 or ref.shape[2] != 3:
         raise Exception(f"reference/target must both be Bx{'K'}x3, got {tuple(ref.shape)} and {tuple(tgt.shape)}")
     B, Kmax, _ = ref.shape
@@ -39,6 +45,8 @@ def get_rigid_transform_3D_batched(reference, target, K=None, device=None):
     q = torch.empty((B, 4), dtype=torch.float64, device=dev)
     call("sv_kabsch_batched", ptr(ref), ptr(tgt), ptr(Kt), c_int(Kmax), c_int(B), ptr(R), ptr(t), ptr(q),
          stream_ptr())
+    if as_tensors:
+        return R, t, q
     return R.cpu().numpy(), t.cpu().numpy(), q.cpu().numpy()
 
 

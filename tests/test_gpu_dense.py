@@ -42,6 +42,11 @@ def test_kabsch_round_trip_large_batch(gpu):
     assert np.abs(R - Rgt).max() < 1e-10 and np.abs(t - tgt_t).max() < 1e-10
     sign = np.sign((qo * q).sum(axis=1, keepdims=True))
     assert np.abs(qo * sign - q).max() < 1e-10
+    # device tensors in, device tensors out (no download, no host synchronisation): the same numbers
+    Rd, td, qd = T.get_rigid_transform_3D_batched(torch.from_numpy(ref).to(gpu), torch.from_numpy(tgt).to(gpu), device=gpu,
+                                                  as_tensors=True)
+    assert Rd.is_cuda and Rd.dtype == torch.float64
+    assert np.array_equal(Rd.cpu().numpy(), R) and np.array_equal(td.cpu().numpy(), t) and np.array_equal(qd.cpu().numpy(), qo)
 
 
 def test_quaternion_average_vs_reference_golden(gpu, golden):
