@@ -219,3 +219,43 @@ def test_wired_colour_key_labels_on_the_oracle(oracle):
     rgb2 = np.clip(preprocess.normalize_colors(sc2["rgb"]), -0.5, 0.05).astype(np.float32)
     ref2 = oracle.predict_segmentation({k: v for k, v in model.state_dict().items()}, sc2["points"], rgb2, 50)
     assert (ref2["label"] == 0).all()
+
+
+def test_bench_groups_consecutive_frames_and_keeps_the_remainder():
+    """bench.run_frames(group=G): K steps stay K frames - consecutive frames of the resident pool go to
+    FramePipeline.prepare_group G at a time, the last group of a region holds the remainder, one group is prepared ahead of
+    the one that runs, and the voxel count / label histogram are sums over all frames (host logic only: stub pipeline)."""
+    import importlib.util
+    import os
+    import types
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    frames = [(torch.full((10 + i, 4), float(i)), torch.zeros(10 + i, 3), None, None, None) for i in range(4)]
+    events = []
+
+    class Pipe:
+        def prepare_group(self, members):
+            ids = [int(c[0, 1]) for c, _ in members]
+            events.append(("prepare", ids))
+            return types.SimpleNamespace(x=types.SimpleNamespace(F=torch.zeros(sum(c.shape[0] for c, _ in members), 1)), ids=ids)
+
+        def run(self, prepared, fn):
+            events.append(("run", prepared.ids))
+            return torch.tensor([len(prepared.ids), 0, 0])
+
+        def drain(self):
+            events.append(("drain",))
+
+    hist = torch.zeros(3, dtype=torch.int64)
+    voxels = bench.run_frames(None, Pipe(), frames, 10, hist, group=4)
+    groups = [[0, 1, 2, 3], [0, 1, 2, 3], [0, 1]]
+    assert [e[1] for e in events if e[0] == "run"] == groups and [e[1] for e in events if e[0] == "prepare"] == groups
+    assert [e[0] for e in events] == ["prepare", "run", "prepare", "run", "prepare", "run", "drain"]  # one group ahead
+    assert voxels == 2 * (10 + 11 + 12 + 13) + 10 + 11 and int(hist[0]) == 10
+    events.clear()
+    assert bench.run_frames(None, Pipe(), frames, 5, None, group=1) == 10 + 11 + 12 + 13 + 10
+    assert [e[1] for e in events if e[0] == "run"] == [[0], [1], [2], [3], [0]]
