@@ -1064,7 +1064,6 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(ConvParams p) {
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, lq = lane >> 4;
   const int K = p.K;
-  const int64_t row0 = ((int64_t)blockIdx.x * 4 + wid) * 16;  // Vpad is a multiple of 128: every wave has its rows
   const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)p.w_bytes, 0x00020000);
   // weights first: they depend on nothing.  Row e of the flat [K * 3][COUT] weight block; rows past the extent (e >= 3 K)
@@ -1073,6 +1072,13 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(ConvParams p) {
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
     b[ks] = buffer_load_floats<NT>(rsrc_w, (uint32_t)(lq * COUT + NT * li) * 4u, (uint32_t)(4 * ks * COUT * 4));
+  // A workgroup of this kernel lives ~1.7 us, and the chip starts only ~126 of them per microsecond (PMC: 0.8 waves per SIMD
+  // on average at 5 542 workgroups): a launch of one workgroup per 64 rows is bound by the dispatcher, not by its memory
+  // chain.  So the grid is capped and every wave walks several sub-tiles (64-row groups blockIdx.x, + gridDim.x, ...) with
+  // its weights loaded once; the LDS block is the wave's own and same-wave LDS traffic is ordered.
+  const int ngroups = (int)(p.Vpad / 64);
+  for (int grp = (int)blockIdx.x; grp < ngroups; grp += (int)gridDim.x) {
+  const int64_t row0 = ((int64_t)grp * 4 + wid) * 16;  // Vpad is a multiple of 128: every wave has its rows
   int o_pre[1][4];
   load_perm_rows<1>(p, row0, lq, o_pre);
   // the wave's 27 x 16 (offset, row) pairs, one per lane and pass: consecutive lanes = consecutive rows of one offset, so
@@ -1114,6 +1120,7 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(ConvParams p) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], b[ks][n], acc[0][n], 0, 0, 0);
   epilogue_buffered<1, NT, true>(p, acc, row0, lq, NT * li, o_pre);
+  }
 }
 
 // ---- the thin layers with the layer's WHOLE weight tensor resident in LDS (round 4; conv_thin_kernel above is kept behind
@@ -1478,7 +1485,10 @@ __global__ __launch_bounds__(256) void conv_first_layer_kernel(ConvParams p) {
 }
 
 static int launch_conv_first_mfma(const ConvParams& p, hipStream_t stream) {
-  hipLaunchKernelGGL((conv_first_mfma_kernel<32>), dim3((unsigned)(p.Vpad / 64)), dim3(256), 0, stream, p);
+  static const int cap = getenv("SV_CONV0_GRID") ? atoi(getenv("SV_CONV0_GRID")) : 768;  // workgroups (see the kernel)
+  const unsigned groups = (unsigned)(p.Vpad / 64);
+  hipLaunchKernelGGL((conv_first_mfma_kernel<32>), dim3(cap > 0 && groups > (unsigned)cap ? (unsigned)cap : groups), dim3(256), 0,
+                     stream, p);
   SV_LAUNCH_CHECK();
   note_instance("conv_first_mfma_kernel<3, 32>|fast=1,ring=0,full=1");
   return SV_OK;
