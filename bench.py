@@ -1161,7 +1161,7 @@ def main():
                        "label_histogram": [int(x) for x in np.diag(agg["confusion"])],
                        "host_placement": pin,
                        "parallelism": f"frame-sharded x{world}, one RCCL all_gather of metrics; per rank: prep stream + "
-                                      f"{args.streams} compute stream(s) alternating between frames"},
+                                      f"{args.streams} compute stream(s) alternating between {'groups of frames' if group > 1 else 'frames'}"},
             "roofline": roofline,
             "kernels_warmup": kernels,
             "per_rank": {k: [round(x, 4) for x in v] for k, v in agg["per_rank"].items() if not k.startswith("strong_")},
